@@ -1,0 +1,81 @@
+/*
+ * scaml_gp.h — C ABI of libscaml_hip.so: the MI355X (gfx950) batched exact-GP inference
+ * hot path of ScaML-GP.
+ *
+ * The reference (boschresearch/Scalable-Meta-Learning-with-Gaussian-Processes) has no
+ * FFI: the path sits behind the Python call surface of scamlgp/model.py and, beneath it,
+ * gpytorch's operator seam.  Each entry point below cites the reference site(s) whose
+ * arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (e.g. PyTorch's
+ *     caching allocator); the library allocates nothing persistent and keeps no state;
+ *   - all matrices/stacks are dense, contiguous, row-major fp64:
+ *       X      (T, N, D)      point stacks            theta (T, D+2) = [l_0..l_{D-1}, os, noise]
+ *       y      (T, N)         standardised targets    L     (T, N, N) lower Cholesky factors
+ *       alpha  (T, N)         (K + noise I)^-1 y
+ *     theta holds CONSTRAINED values (lengthscales, outputscale, noise variance);
+ *   - `n_points` (T) int32, may be NULL: per-task number of valid points n_t <= N (ragged
+ *     tasks; rows/cols >= n_t are treated as an identity block and never written);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); work is only
+ *     enqueued, never synchronised;
+ *   - return value: 0 ok; <0 bad argument (SCAML_E_*); never throws.  Numerical status
+ *     is per task in the caller-provided `info` (LAPACK convention: info[t] = k > 0 means
+ *     the leading minor of order k is not positive definite after the last jitter try).
+ */
+#ifndef SCAML_GP_H
+#define SCAML_GP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCAML_KIND_RBF 0      /* gpytorch RBFKernel:    exp(-r^2/2)                        */
+#define SCAML_KIND_MATERN52 1 /* gpytorch MaternKernel(nu=2.5): (1+√5r+5r²/3)exp(-√5r)      */
+
+#define SCAML_OK 0
+#define SCAML_E_BADARG -1      /* NULL pointer / negative size                              */
+#define SCAML_E_TOOLARGE -2    /* N or D beyond what the kernels support (see *_max_*)      */
+#define SCAML_E_LAUNCH -3      /* hipLaunch / attribute call failed (see scaml_last_error)  */
+
+/* flags for scaml_gp_fit_fused_f64 */
+#define SCAML_FIT_STORE_L 1u     /* write L (T,N,N); without it only alpha + scalars (MLL-only mode) */
+#define SCAML_FIT_ZERO_UPPER 2u  /* also write zeros to the strict upper triangle of L       */
+#define SCAML_FIT_NO_RETRY 4u    /* single attempt: no in-kernel jitter escalation           */
+
+/* Library / limits ------------------------------------------------------------------ */
+int scaml_version(void);            /* 10000*major + 100*minor + patch */
+const char* scaml_last_error(void); /* text of the last HIP error seen by this thread    */
+int scaml_fit_max_n(void);          /* largest N of the register-resident fused fit       */
+int scaml_fit_max_d(int N);         /* largest D for that N (LDS budget)                  */
+
+/*
+ * (3) Fused "task-posterior": kernel matrix + noise, jittered Cholesky, alpha, quad,
+ * logdet and the marginal log-likelihood for a stack of T independent tasks.
+ * Replaces, for the whole stack at once, the per-task chain the reference runs inside
+ *   scamlgp/model.py:176-188  (for task in meta_data: SingleTaskGP + optimize_marginal_likelihood)
+ *   scamlgp/utils.py:171-177  (ExactMarginalLogLikelihood -> MVN.log_prob -> inv_quad_logdet ->
+ *                              psd_safe_cholesky -> torch.linalg.cholesky_ex / solve_triangular)
+ * with the kernels of scamlgp/model.py:36-70 / :73-105 and the noise of :25-33.
+ *   quad[t]   = y^T (K+noise I)^-1 y          logdet[t] = log det (K+noise I)
+ *   mll[t]    = -(quad + logdet + n_t log 2pi) / (2 n_t)      (no prior terms)
+ * Jitter: like linear_operator's psd_safe_cholesky the first attempt adds nothing; a task
+ * whose factorisation hits a non-positive pivot is retried IN-KERNEL with 1e-8, 1e-7, 1e-6
+ * added to its diagonal (only that task); jitter_used[t] reports the value that succeeded,
+ * info[t] > 0 that all attempts failed.  `jitter_in` (T) may be NULL; if given it is added to
+ * every attempt (caller-controlled extra jitter).
+ * Outputs L, alpha, quad, logdet, mll, jitter_used may individually be NULL (not written);
+ * info must not be NULL.
+ */
+int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta,
+                           const int32_t* n_points, const double* jitter_in,
+                           int T, int N, int D, int kind,
+                           double* L, double* alpha, double* quad, double* logdet, double* mll,
+                           int32_t* info, double* jitter_used, unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCAML_GP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libscaml_hip.so (the C ABI declared in include/scaml_gp.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a symbol cannot be
+resolved, importing this module raises.  Build it with ``python -c "import __graft_entry__ as
+g; g.build()"`` from the repository root (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_uint, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libscaml_hip.so")
+
+KIND_RBF = 0
+KIND_MATERN52 = 1
+
+FIT_STORE_L = 1
+FIT_ZERO_UPPER = 2
+FIT_NO_RETRY = 4
+
+E_BADARG = -1
+E_TOOLARGE = -2
+E_LAUNCH = -3
+
+_dp = c_void_p  # device pointers travel as integers
+
+
+class ScamlLibraryError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ScamlLibraryError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run __graft_entry__.build()); there is no CPU fallback for the GP hot path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.scaml_version.restype = c_int
+    lib.scaml_version.argtypes = []
+    lib.scaml_last_error.restype = c_char_p
+    lib.scaml_last_error.argtypes = []
+    lib.scaml_fit_max_n.restype = c_int
+    lib.scaml_fit_max_n.argtypes = []
+    lib.scaml_fit_max_d.restype = c_int
+    lib.scaml_fit_max_d.argtypes = [c_int]
+    lib.scaml_gp_fit_fused_f64.restype = c_int
+    lib.scaml_gp_fit_fused_f64.argtypes = [
+        _dp, _dp, _dp, _dp, _dp,  # X, y, theta, n_points, jitter_in
+        c_int, c_int, c_int, c_int,  # T, N, D, kind
+        _dp, _dp, _dp, _dp, _dp,  # L, alpha, quad, logdet, mll
+        _dp, _dp, c_uint, c_void_p,  # info, jitter_used, flags, stream
+    ]
+    return lib
+
+
+lib = _load()
+
+# Every symbol include/scaml_gp.h declares; tests check the built library exports them all.
+EXPORTED_SYMBOLS = (
+    "scaml_version",
+    "scaml_last_error",
+    "scaml_fit_max_n",
+    "scaml_fit_max_d",
+    "scaml_gp_fit_fused_f64",
+)
+
+
+def check_rc(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc == E_BADARG:
+        raise ValueError(f"{what}: bad argument")
+    if rc == E_TOOLARGE:
+        raise ValueError(f"{what}: problem size exceeds kernel limits")
+    msg = lib.scaml_last_error().decode("utf-8", "replace")
+    raise RuntimeError(f"{what}: HIP launch failed ({msg})")

@@ -1,0 +1,106 @@
+"""Torch-tensor front end of the C ABI (device memory, streams; no arithmetic here).
+
+Every function takes CUDA(=HIP) fp64 tensors, passes raw device pointers plus the current
+stream to libscaml_hip.so and returns freshly allocated output tensors.  Nothing is
+synchronised; ``info`` tensors stay on the device until the caller inspects them.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import KIND_MATERN52, KIND_RBF  # noqa: F401  (re-export)
+
+
+class NotPSDError(RuntimeError):
+    """Cholesky failed for at least one task even after the jitter escalation
+    (mirrors linear_operator.utils.errors.NotPSDError, a RuntimeError the reference
+    catches at scamlgp/utils.py:180,193)."""
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _check(t: torch.Tensor, name: str, shape=None, dtype=torch.float64) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); the GP hot path has no CPU fallback")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype} (got {t.dtype})")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)} (got {tuple(t.shape)})")
+    return t.contiguous()
+
+
+def _stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gp_fit_fused(
+    X: torch.Tensor,
+    y: torch.Tensor,
+    theta: torch.Tensor,
+    kind: int,
+    n_points: Optional[torch.Tensor] = None,
+    jitter: Optional[torch.Tensor] = None,
+    store_L: bool = True,
+    zero_upper: bool = True,
+    retry: bool = True,
+    want_alpha: bool = True,
+) -> Dict[str, torch.Tensor]:
+    """K + noise, jittered Cholesky, alpha, quad, logdet, MLL for a stack of tasks.
+
+    X (T, N, D), y (T, N), theta (T, D+2) = [lengthscales, outputscale, noise] (constrained).
+    Returns dict(L, alpha, quad, logdet, mll, info, jitter); ``L`` is None when store_L=False.
+    One launch of ``scaml_gp_fit_fused_f64`` (include/scaml_gp.h).
+    """
+    if X.dim() != 3:
+        raise ValueError("X must be (T, N, D)")
+    T, N, D = X.shape
+    X = _check(X, "X")
+    y = _check(y, "y", (T, N))
+    theta = _check(theta, "theta", (T, D + 2))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    if jitter is not None:
+        jitter = _check(jitter, "jitter", (T,))
+    dev = X.device
+    with torch.cuda.device(dev):
+        L = torch.empty((T, N, N), dtype=torch.float64, device=dev) if store_L else None
+        alpha = torch.empty((T, N), dtype=torch.float64, device=dev) if want_alpha else None
+        quad = torch.empty((T,), dtype=torch.float64, device=dev)
+        logdet = torch.empty((T,), dtype=torch.float64, device=dev)
+        mll = torch.empty((T,), dtype=torch.float64, device=dev)
+        info = torch.empty((T,), dtype=torch.int32, device=dev)
+        jit_used = torch.empty((T,), dtype=torch.float64, device=dev)
+        if n_points is not None and want_alpha:
+            alpha.zero_()
+        flags = 0
+        if store_L:
+            flags |= _lib.FIT_STORE_L
+            if zero_upper:
+                flags |= _lib.FIT_ZERO_UPPER
+            if n_points is not None:
+                L.zero_()
+        if not retry:
+            flags |= _lib.FIT_NO_RETRY
+        rc = _lib.lib.scaml_gp_fit_fused_f64(
+            _ptr(X), _ptr(y), _ptr(theta), _ptr(n_points), _ptr(jitter),
+            T, N, D, int(kind),
+            _ptr(L), _ptr(alpha), _ptr(quad), _ptr(logdet), _ptr(mll),
+            _ptr(info), _ptr(jit_used), flags, _stream_handle(),
+        )
+    _lib.check_rc(rc, "scaml_gp_fit_fused_f64")
+    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used)
+
+
+def raise_if_not_psd(info: torch.Tensor) -> None:
+    """Host-side check of the per-task status (one device->host sync)."""
+    bad = torch.nonzero(info > 0).flatten()
+    if bad.numel():
+        raise NotPSDError(
+            f"Matrix not positive definite after repeatedly adding jitter up to 1.0e-06 "
+            f"(tasks {bad.tolist()[:8]}{'...' if bad.numel() > 8 else ''})."
+        )

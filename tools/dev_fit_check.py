@@ -1,0 +1,78 @@
+"""Developer check: fused fit kernel vs the CPU oracle on a few shapes (needs a GPU)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd"))
+sys.path.insert(0, ROOT)
+import torch
+from scamlgp_amd import ops
+from oracle import gp_oracle as O
+
+torch.manual_seed(0)
+dev = torch.device("cuda:0")
+
+def make(T, N, D, ls=0.5, noise=1e-3):
+    X = torch.rand(T, N, D, dtype=torch.float64)
+    w = torch.randn(T, D, 1, dtype=torch.float64)
+    y = torch.sin(3 * X @ w).squeeze(-1) + 0.1 * torch.randn(T, N, dtype=torch.float64)
+    y = (y - y.mean(-1, keepdim=True)) / y.std(-1, keepdim=True)
+    theta = torch.cat([torch.full((T, D), ls) * (0.8 + 0.4 * torch.rand(T, D)), torch.full((T, 1), 1.0), torch.full((T, 1), noise)], 1).double()
+    return X, y, theta
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+ok = True
+for (T, N, D, kind) in [(4, 32, 2, 0), (3, 20, 3, 1), (5, 64, 2, 0), (4, 100, 5, 1), (6, 128, 2, 0), (3, 200, 8, 1), (8, 256, 8, 1), (8, 256, 8, 0)]:
+    X, y, theta = make(T, N, D)
+    ref = O.gp_fit_stack_loop(X, y, theta, kind, dist="direct")
+    out = ops.gp_fit_fused(X.to(dev), y.to(dev), theta.to(dev), kind)
+    torch.cuda.synchronize()
+    info = out["info"].cpu()
+    eL = rel(out["L"].cpu(), ref["L"]); ea = rel(out["alpha"].cpu(), ref["alpha"])
+    eq = rel(out["quad"].cpu(), ref["quad"]); eld = rel(out["logdet"].cpu(), ref["logdet"]); em = rel(out["mll"].cpu(), ref["mll"])
+    print(f"T={T} N={N} D={D} kind={kind} info={info.tolist()} jit={out['jitter'].cpu().tolist()[:2]} relerr L={eL:.2e} alpha={ea:.2e} quad={eq:.2e} logdet={eld:.2e} mll={em:.2e}")
+    ok &= eL < 1e-9 and ea < 1e-6 and em < 1e-9 and not info.any()
+
+# ragged
+T, N, D, kind = 6, 100, 4, 1
+X, y, theta = make(T, N, D)
+npts = torch.tensor([100, 1, 17, 64, 99, 33], dtype=torch.int32)
+out = ops.gp_fit_fused(X.to(dev), y.to(dev), theta.to(dev), kind, n_points=npts.to(dev))
+for t in range(T):
+    n = int(npts[t])
+    r = O.gp_fit(X[t, :n], y[t, :n], theta[t], kind, dist="direct")
+    eL = rel(out["L"][t, :n, :n].cpu(), r["L"]); ea = rel(out["alpha"][t, :n].cpu(), r["alpha"]); em = rel(out["mll"][t].cpu(), r["mll"])
+    print(f"ragged t={t} n={n} L={eL:.2e} alpha={ea:.2e} mll={em:.2e}")
+    ok &= eL < 1e-9 and ea < 1e-6 and em < 1e-9
+
+# jitter path: duplicated points with tiny noise
+T, N, D, kind = 3, 64, 2, 0
+X, y, theta = make(T, N, D, noise=1e-8)
+X[1, 32:] = X[1, :32]  # exact duplicates -> singular K + 1e-8 I (may or may not fail)
+theta[1, -1] = 1e-8
+theta[:, :D] = 2.0
+out = ops.gp_fit_fused(X.to(dev), y.to(dev), theta.to(dev), kind)
+print("jitter test info", out["info"].cpu().tolist(), "jitter", out["jitter"].cpu().tolist())
+try:
+    ref = O.gp_fit_stack_loop(X, y, theta, kind, dist="direct")
+    print("oracle jitter", ref["jitter"].tolist(), "mll rel", rel(out["mll"].cpu(), ref["mll"]))
+except Exception as e:
+    print("oracle raised", e)
+
+# timing at the headline shape
+T, N, D, kind = 256, 256, 8, 1
+X, y, theta = make(T, N, D)
+Xd, yd, td = X.to(dev), y.to(dev), theta.to(dev)
+for _ in range(3):
+    out = ops.gp_fit_fused(Xd, yd, td, kind)
+torch.cuda.synchronize()
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    out = ops.gp_fit_fused(Xd, yd, td, kind)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 20
+print(f"T=256 N=256 D=8 matern: {ms*1e3:.1f} us/launch -> {T/ms*1e3:.3e} task-posteriors/s; info any={out['info'].any().item()}")
+t0 = time.perf_counter(); ref = O.gp_fit_stack_loop(X[:32], y[:32], theta[:32], kind); t1 = time.perf_counter()
+print(f"cpu oracle loop 32 tasks: {(t1-t0)*1e3:.1f} ms -> {32/(t1-t0):.1f} tasks/s; mll relerr vs gpu {rel(out['mll'][:32].cpu(), ref['mll']):.2e} alpha {rel(out['alpha'][:32].cpu(), ref['alpha']):.2e}")
+print("ALL OK" if ok else "FAILURES")
