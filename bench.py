@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — task-posteriors/sec of the fused GP hot path (K + Cholesky + solves + MLL).
+
+One "step" = one pass of the hot path over one batch of synthetic input: a single launch of
+scaml_gp_fit_fused_f64 over T = 256 meta-tasks x N = 256 points x D = 8, Matern-5/2 + ARD
+(BASELINE.json configs[2], the configuration the metric is quoted on), inputs resident in HBM.
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
+owns its own 256-task shard (weak scaling) and each step also all-reduces the summed marginal
+likelihood across ranks (the path's only exchange step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     — algorithmic fp64 flops per launch / measured kernel duration vs the fp64 MFMA peak
+  cpu_baseline — the CPU oracle (oracle/gp_oracle.py, the reference's op sequence in torch fp64)
+                 timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd"))
+
+T_PER_GPU, N_POINTS, DIM = 256, 256, 8
+PEAK_FP64_TFLOPS = 78.6  # MI355X fp64 matrix = vector peak: 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz
+                         # (measured: one v_mfma_f64_16x16x4_f64 per 64 cycles per SIMD, profiles/r01_probe_f64_rates.txt)
+
+
+def algorithmic_flops_per_task(N: int, D: int, matern: bool) -> float:
+    """N^3/3 [POTRF] + N(N+1)/2 (4D + c_k) [kernel, symmetric half]
+    + 2 N^2 [two TRSV] + 3 N [quad, logdet]; c_k = 8 Matern-5/2, 2 RBF; FMA = 2."""
+    ck = 8 if matern else 2
+    return N ** 3 / 3.0 + N * (N + 1) / 2.0 * (4 * D + ck) + 2.0 * N * N + 3.0 * N
+
+
+def algorithmic_bytes_per_task(N: int, D: int) -> float:
+    """Read X, y, theta; write full L (with zero upper triangle), alpha, 3 scalars, info, jitter."""
+    return 8.0 * (N * D + N + D + 2) + 8.0 * (N * N + N + 3) + 4 + 8
+
+
+def make_inputs(rank: int, device):
+    import numpy as np
+    import torch
+    from scamlgp_amd import synthetic
+
+    d = synthetic.smooth_field_task_stack(T_PER_GPU, N_POINTS, DIM, seed=1234 + rank)
+    ys, _, _ = synthetic.standardize_rows(d["Y"])
+    rng = np.random.default_rng(4321 + rank)
+    # reference inits (scamlgp/model.py:55, 67, 31): lengthscale 0.5 (ARD, +-20 % per dim so the
+    # ARD path is exercised), outputscale 1.0, noise 1e-3
+    theta = np.concatenate(
+        [0.5 * (1 + 0.4 * (rng.uniform(size=(T_PER_GPU, DIM)) - 0.5)), np.full((T_PER_GPU, 1), 1.0), np.full((T_PER_GPU, 1), 1e-3)], 1)
+    X = torch.from_numpy(d["X"])
+    y = torch.from_numpy(ys)
+    th = torch.from_numpy(theta)
+    return (X, y, th), (X.to(device), y.to(device), th.to(device))
+
+
+def cpu_baseline(host_inputs, budget_s: float = 12.0):
+    """Time the oracle's per-task loop (the reference's shape of work, scamlgp/model.py:176-188)
+    on the host cores over a bounded sample of the bench workload."""
+    import torch
+    from oracle import gp_oracle as O
+
+    X, y, th = host_inputs
+    cores = torch.get_num_threads()
+    O.gp_fit_stack_loop(X[:2], y[:2], th[:2], O.KIND_MATERN52)  # warm-up
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        lo = done % T_PER_GPU
+        hi = min(lo + 8, T_PER_GPU)
+        O.gp_fit_stack_loop(X[lo:hi], y[lo:hi], th[lo:hi], O.KIND_MATERN52)
+        done += hi - lo
+        el = time.perf_counter() - t0
+        if el > budget_s or done >= 4 * T_PER_GPU:
+            break
+    return dict(value=done / el, unit="task-posteriors/s", cores=cores, kind="port",
+                sample=f"{done} tasks of the bench workload (per-task torch-fp64 loop, {el:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+
+    entry.build()
+    from scamlgp_amd import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    host_inputs, (X, y, th) = make_inputs(rank, device)
+    kind = ops.KIND_MATERN52
+    out = ops.gp_fit_fused(X, y, th, kind)  # allocates the output buffers once
+    total = args.warmup + args.steps
+    sums = torch.zeros(total, 1, dtype=torch.float64, device=device)
+    works = []
+
+    def step(i):
+        ops.gp_fit_fused(X, y, th, kind, out=out)
+        if distributed:
+            torch.sum(out["mll"], dim=0, keepdim=True, out=sums[i])
+            works.append(dist.all_reduce(sums[i], async_op=True))
+
+    def fence():
+        for w in works:
+            w.wait()
+        works.clear()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launch stream only: avg duration per fused-fit launch
+
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ok = not bool(out["info"].any().item())
+
+    if rank == 0:
+        flops = algorithmic_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        res = {
+            "metric": "task-posteriors/sec (K+chol+solve+MLL) at T=256,N=256",
+            "value": world * T_PER_GPU * args.steps / elapsed,
+            "unit": "task-posteriors/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[2]: 256 meta-tasks x 256 points x d=8, Matern-5/2 + ARD, per GPU "
+                            "(fused K + jittered Cholesky + alpha + MLL, L stored)",
+                "tasks_per_gpu": T_PER_GPU, "points": N_POINTS, "dim": DIM, "kernel": "matern52",
+                "sharding": "task shards, one all-reduce of the summed MLL per step" if distributed else "single GPU",
+                "all_tasks_psd": ok,
+            },
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                "kernel": "gp_fit_fused_kernel<16,8,matern52>",
+                "kernel_ms": kernel_ms,
+                "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": algorithmic_bytes_per_task(N_POINTS, DIM) * T_PER_GPU,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(host_inputs)
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -263,7 +263,7 @@ def mll_with_source_priors(X, y, theta, kind, dist="gpytorch") -> torch.Tensor:
     return out["mll"] + source_gp_log_prior(theta) / N
 
 
-def mll_value_and_grad_raw(X, y, raw, kind, bounds, dist="gpytorch", with_priors=True):
+def mll_value_and_grad_raw(X, y, raw, kind, bounds, with_priors=True):
     """Value and gradient of the MLL w.r.t. the RAW (unconstrained) parameters through the
     sigmoid-Interval transform, by autograd — the oracle for the analytic HIP backward.
 
@@ -273,8 +273,7 @@ def mll_value_and_grad_raw(X, y, raw, kind, bounds, dist="gpytorch", with_priors
     hi = torch.tensor([b[1] for b in bounds], dtype=raw.dtype)
     theta = lo + (hi - lo) * torch.sigmoid(raw)
     N, D = X.shape
-    K = kernel_matrix(X, None, theta[:D], theta[D], kind, "direct" if dist == "direct" else "gpytorch_grad")\
-        if False else _kernel_matrix_grad(X, theta, kind)
+    K = _kernel_matrix_grad(X, theta, kind)
     K = K + theta[D + 1] * torch.eye(N, dtype=X.dtype)
     L = torch.linalg.cholesky(K)
     v = torch.linalg.solve_triangular(L, y.unsqueeze(-1), upper=False)
@@ -312,11 +311,8 @@ def source_posterior(
     Sigma = s^2 (k(x,x) - V^T V), V = L^-1 K_*^T.  No observation noise."""
     D = X.shape[-1]
     ls, os_ = theta[:D], theta[D]
-    if kind == KIND_MATERN52:
-        # MaternKernel centres on the mean of its first argument (x here): translation only
-        Ks = kernel_matrix(xq, X, ls, os_, kind, dist)
-    else:
-        Ks = kernel_matrix(xq, X, ls, os_, kind, dist)
+    # (MaternKernel centres on the mean of its first argument, xq here: a pure translation)
+    Ks = kernel_matrix(xq, X, ls, os_, kind, dist)
     mu = Ks @ alpha
     V = torch.linalg.solve_triangular(L, Ks.transpose(-1, -2), upper=False)
     if full_cov:

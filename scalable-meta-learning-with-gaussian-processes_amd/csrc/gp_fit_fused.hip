@@ -7,20 +7,41 @@
 //   scamlgp/model.py:176-188 -> scamlgp/utils.py:171-177 -> gpytorch ExactMarginalLogLikelihood
 //   -> linear_operator psd_safe_cholesky -> torch.linalg.cholesky_ex / solve_triangular.
 //
-// Design: the kernel matrix never exists in memory.  The trailing matrix of the
-// right-looking Cholesky lives in MFMA accumulator registers: the lower triangle is cut into
-// 16x16 tiles, tile t (column-major over the triangle) belongs to wave t % W, slot t / W, and is
-// held in the C/D layout of v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 * reg).
-// Each lane evaluates the kernel function for the four elements it owns straight into those
-// registers.  Per 16-column panel: (P1) owners spill the panel column to LDS, (P2) wave 0
-// factors the 16x16 diagonal block and forward-substitutes y, (P3) one thread per row solves
-// the sub-diagonal rows against the block, (P4) every wave applies the rank-16 update to its
-// tiles with 4 MFMAs per tile, operands read from the LDS panel; finished L tiles are written
-// to HBM from registers as 128-byte row segments.  alpha comes from a blocked back-substitution
-// over the L tiles still held in registers.  A failed pivot restarts the task in-kernel with the
-// next jitter (1e-8, 1e-7, 1e-6), as linear_operator's psd_safe_cholesky does on the host.
+// Design.  The kernel matrix never exists in memory: the trailing matrix of a
+// right-looking Cholesky lives in MFMA accumulator registers.  The lower triangle is cut into
+// 16x16 tiles; tile t (column-major over the triangle) belongs to update wave t % WU, slot t / WU,
+// in the C/D layout of v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 * reg), and
+// every lane evaluates the kernel function for the four elements it owns straight into it.
+// Waves are specialised: WU "update" waves own tiles; one "panel" wave owns none and factors the
+// 16x16 diagonal blocks.  Per 16-column panel k (diagonal block factored, rows below raw in LDS):
+//   T   owners of column k form L_ik = A_ik W^T with 4 MFMAs per tile (W = L_kk^-1 from the panel
+//       wave), put the final tiles back into the LDS panel and write them to HBM from registers
+//       (128-byte row segments; the mirrored upper tile is written as zeros by the same lanes)
+//   U1  tiles of column k+1 get their rank-16 update first and are spilled to the other LDS panel
+//       (meanwhile the panel wave folds panel k into the running right-hand side y)
+//   U2  all remaining tiles get the rank-16 update (4 MFMAs per tile, operands from the LDS
+//       panel) WHILE the panel wave factors diagonal block k+1 (one-panel lookahead): 16 rank-1
+//       MFMA updates on the symmetric block, the next pivot computed ahead on the VALU so the
+//       64-cycle MFMA latency stays off the pivot chain; a second accumulator receives the same
+//       row operations and ends as L_kk^-1, which also gives v_k = L_kk^-1 y_k as a mat-vec.
+// alpha comes from a blocked back-substitution over the L tiles still held in registers.  A
+// failed pivot restarts the task in-kernel with the next jitter (1e-8, 1e-7, 1e-6), as
+// linear_operator's psd_safe_cholesky does on the host.
 #include "scaml_common.hpp"
 #include "../../include/scaml_gp.h"
+
+#ifdef SCAML_STAMPS
+// Diagnostic build only (tools/build_stamps.sh): thread 0 of every workgroup accumulates
+// s_memtime deltas per phase into a caller-provided buffer [T][16].  Never in libscaml_hip.so.
+__device__ long long* g_stamp_buf = nullptr;
+#define STAMP_DECL long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[16] = {0}
+#define STAMP(i) do { long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; } while (0)
+#define STAMP_FLUSH(task) do { if (g_stamp_buf && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_stamp_buf[(task) * 16 + i_] = st_acc[i_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(task)
+#endif
 
 namespace scaml {
 
@@ -41,21 +62,156 @@ struct FitParams {
   unsigned flags;
 };
 
-template <int NB, int W, int KIND>
-__global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
-  constexpr int NP = NB * 16;               // padded matrix order
-  constexpr int NT = NB * (NB + 1) / 2;     // lower-triangular tiles
-  constexpr int SLOTS = (NT + W - 1) / W;   // tiles per wave
-  constexpr int PITCH = NP + 16;            // panel row pitch (doubles): conflict-free operand reads
-  constexpr int NTHREADS = W * 64;
-  static_assert(NTHREADS >= NP, "one thread per matrix row is required");
+// LDS panel layout: PANEL[row * PP + c], PP = 17 doubles.  With this pitch the MFMA operand reads
+// (lane -> row 16t + (lane & 15), column 4m + (lane >> 4)), the C/D-layout tile spills/reloads
+// (lane -> row (lane >> 4) + 4g, column lane & 15) and the per-row reads are all bank-conflict free.
+constexpr int PP = 17;
+
+__device__ __forceinline__ int opaque_s(int v) {
+  asm volatile("" : "+s"(v));  // keeps per-slot address arithmetic from being hoisted out of the panel loop
+  return v;
+}
+
+// ---- panel wave: Cholesky of the 16x16 diagonal block k, its inverse, and v_k = L_kk^-1 y_k ----
+// panel rows 16k..16k+15 hold the symmetric trailing block (both triangles).  The block sits in
+// one MFMA accumulator (C/D layout); step c scales row c (= column c by symmetry, already in
+// operand position on lane group c & 3), applies the rank-1 update with ONE MFMA and forms the
+// next pivot ahead of it on the VALU, so the 64-cycle MFMA latency is off the pivot chain.  A
+// second accumulator R (initially I) receives the same row operations and ends as W = L_kk^-1.
+// Outputs: panel rows <- L_kk (zero above the diagonal), Wk[c * PP + j] = W[c][j], rinv, dl, vv.
+// Returns 0 or the 1-based global index of the first non-positive / out-of-range pivot.
+__device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double* rinv, double* dl, double* vv,
+                                               const double* ytil, int k, int lane) {
+  const int lc = lane & 15, lq = lane >> 4;
+  d4_t a, R;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    a[g] = panel[(16 * k + lq + 4 * g) * PP + lc];
+    R[g] = (lc == lq + 4 * g) ? 1.0 : 0.0;
+  }
+  int bad = 0;
+  double dpiv = readlane_f64(a[0], 0);
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int g = c & 3, rg = c >> 2;
+    if (!(dpiv >= 1e-30 && dpiv <= 1e30)) {  // non-positive, NaN or outside the seeded rsqrt range
+      if (!bad) bad = 16 * k + c + 1;
+      dpiv = 1.0;
+    }
+    const double ri = rsqrt_seeded(dpiv);
+    const bool mine = lq == g;
+    const double lcol = (mine && lc >= c) ? a[rg] * ri : 0.0;  // L[lc][c]
+    const double wrow = mine ? R[rg] * ri : 0.0;               // W[c][lc]
+    if (c < 15) {
+      const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
+      const double lnext = readlane_f64(lcol, 16 * g + c + 1);
+      const double anext = readlane_f64(a[rg1], 16 * g1 + c + 1);
+      dpiv = __builtin_fma(-lnext, lnext, anext);
+      a = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcol, lcol, a, 0, 0, 0);
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcol, wrow, R, 0, 0, 0);
+    }
+    if (mine) {
+      panel[(16 * k + lc) * PP + c] = lcol;
+      Wk[c * PP + lc] = wrow;
+    }
+    if (lane == 16 * g + c) {
+      rinv[16 * k + c] = ri;
+      dl[16 * k + c] = lcol;
+    }
+  }
+  // v_k = W y_k (row lc of W per lane; lane groups replicate)
+  double v = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) v = __builtin_fma(Wk[lc * PP + c], ytil[16 * k + c], v);
+  if (lq == 0) vv[16 * k + lc] = v;
+  return bad;
+}
+
+// ---- hand-managed accumulator tiles ------------------------------------------------------------
+// The trailing-matrix tiles live in AGPRs a[0:159] that the COMPILER NEVER SEES as values: every
+// access is an asm statement naming the physical registers (csrc/tile_regs.inc) and listing them
+// as clobbers.  Why: with the tiles as C++ values (builtin MFMA, or asm with tied "+v"/"+a"
+// operands) hipcc's register allocator kept a second VGPR copy of tiles around the wave-uniform
+// branches of the panel loop, ran out of registers and spilled tiles to scratch every phase
+// (568-876 bytes/lane, 5x slower; profiles/r01_notes.md).  Hand-managed, the compiler only has
+// to fit its own temporaries into the VGPR half (capped with amdgpu_num_vgpr so that VGPRs + 160
+// AGPRs stay within the 256 registers a wave gets at 2 waves/SIMD).
+// Hazards hipcc cannot see inside asm (CDNA3/4 ISA 4.5, DGEMM rows): dependent MFMAs on one tile
+// issue back to back; MFMA_DRAIN (19 wait states) must separate the last MFMA on a tile from any
+// v_accvgpr_read/write of it; 2 wait states cover a VALU-written operand feeding an MFMA.
+#include "tile_regs.inc"
+
+#define SCAML_CLOB8(r0, r1, r2, r3, r4, r5, r6, r7) "a" #r0, "a" #r1, "a" #r2, "a" #r3, "a" #r4, "a" #r5, "a" #r6, "a" #r7
+#define SCAML_TILE(r0, r7) "a[" #r0 ":" #r7 "]"
+
+// tile <- (d0, d1, d2, d3): element g is the value for row (lane >> 4) + 4g, column lane & 15
+#define TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, d0, d1, d2, d3)                                   \
+  asm volatile("v_accvgpr_write_b32 a" #r0 ", %0\n\tv_accvgpr_write_b32 a" #r1 ", %1\n\t"         \
+               "v_accvgpr_write_b32 a" #r2 ", %2\n\tv_accvgpr_write_b32 a" #r3 ", %3\n\t"         \
+               "v_accvgpr_write_b32 a" #r4 ", %4\n\tv_accvgpr_write_b32 a" #r5 ", %5\n\t"         \
+               "v_accvgpr_write_b32 a" #r6 ", %6\n\tv_accvgpr_write_b32 a" #r7 ", %7"             \
+               :                                                                                   \
+               : "v"(__double2loint(d0)), "v"(__double2hiint(d0)), "v"(__double2loint(d1)),        \
+                 "v"(__double2hiint(d1)), "v"(__double2loint(d2)), "v"(__double2hiint(d2)),        \
+                 "v"(__double2loint(d3)), "v"(__double2hiint(d3))                                  \
+               : SCAML_CLOB8(r0, r1, r2, r3, r4, r5, r6, r7))
+
+// (d0, d1, d2, d3) <- tile
+#define TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, d0, d1, d2, d3)                                   \
+  do {                                                                                             \
+    int l0_, h0_, l1_, h1_, l2_, h2_, l3_, h3_;                                                    \
+    asm volatile("v_accvgpr_read_b32 %0, a" #r0 "\n\tv_accvgpr_read_b32 %1, a" #r1 "\n\t"         \
+                 "v_accvgpr_read_b32 %2, a" #r2 "\n\tv_accvgpr_read_b32 %3, a" #r3 "\n\t"         \
+                 "v_accvgpr_read_b32 %4, a" #r4 "\n\tv_accvgpr_read_b32 %5, a" #r5 "\n\t"         \
+                 "v_accvgpr_read_b32 %6, a" #r6 "\n\tv_accvgpr_read_b32 %7, a" #r7                 \
+                 : "=v"(l0_), "=v"(h0_), "=v"(l1_), "=v"(h1_), "=v"(l2_), "=v"(h2_), "=v"(l3_),    \
+                   "=v"(h3_));                                                                     \
+    d0 = __hiloint2double(h0_, l0_);                                                               \
+    d1 = __hiloint2double(h1_, l1_);                                                               \
+    d2 = __hiloint2double(h2_, l2_);                                                               \
+    d3 = __hiloint2double(h3_, l3_);                                                               \
+  } while (0)
+
+// tile -= A * B over four k-steps (rank-16 update): neg:[1,0,0] negates the A operand in the MFMA
+#define TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, a0, a1, a2, a3, b0, b1, b2, b3)             \
+  asm volatile("s_nop 1\n\t"                                                                       \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %0, %4, " SCAML_TILE(r0, r7) " neg:[1,0,0]\n\t" \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %1, %5, " SCAML_TILE(r0, r7) " neg:[1,0,0]\n\t" \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %2, %6, " SCAML_TILE(r0, r7) " neg:[1,0,0]\n\t" \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %3, %7, " SCAML_TILE(r0, r7) " neg:[1,0,0]"     \
+               :                                                                                   \
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3)            \
+               : SCAML_CLOB8(r0, r1, r2, r3, r4, r5, r6, r7))
+
+// tile = A * B over four k-steps (first MFMA starts from the inline constant 0)
+#define TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, a0, a1, a2, a3, b0, b1, b2, b3)             \
+  asm volatile("s_nop 1\n\t"                                                                       \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %0, %4, 0\n\t"                      \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %1, %5, " SCAML_TILE(r0, r7) "\n\t" \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %2, %6, " SCAML_TILE(r0, r7) "\n\t" \
+               "v_mfma_f64_16x16x4_f64 " SCAML_TILE(r0, r7) ", %3, %7, " SCAML_TILE(r0, r7)        \
+               :                                                                                   \
+               : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3)            \
+               : SCAML_CLOB8(r0, r1, r2, r3, r4, r5, r6, r7))
+
+#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
+
+template <int NB, int WU, int KIND>
+__global__ __launch_bounds__((WU + 1) * 64) __attribute__((amdgpu_num_vgpr(96)))
+void gp_fit_fused_kernel(FitParams p) {
+  constexpr int NP = NB * 16;                 // padded matrix order
+  constexpr int NT = NB * (NB + 1) / 2;       // lower-triangular tiles
+  constexpr int SLOTS = (NT + WU - 1) / WU;   // tiles per update wave
+  constexpr int PANEL = NP * PP;              // doubles per LDS panel buffer
+  constexpr int NTHREADS = (WU + 1) * 64;
+  static_assert(SLOTS <= 20, "tile_regs.inc provides 20 accumulator tiles");
 
   extern __shared__ double lds[];
-  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][16][PITCH] + LkkAll[NB][16][16] afterwards
+  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][NP][PP] + WAll[NB][16][PP] afterwards
   double* xsT = lds;
   double* PT = lds;
-  double* LkkAll = lds + 2 * 16 * PITCH;
-  const int regionA = (p.D * NP > 2 * 16 * PITCH + NB * 256) ? p.D * NP : 2 * 16 * PITCH + NB * 256;
+  double* WAll = lds + 2 * PANEL;
+  const int regionA = (p.D * NP > 2 * PANEL + NB * 16 * PP) ? p.D * NP : 2 * PANEL + NB * 16 * PP;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
   double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
@@ -68,6 +224,7 @@ __global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_panel = wave == WU;
   const int lc = lane & 15;   // tile column owned by this lane
   const int lq = lane >> 4;   // tile row group: rows lq + 4 * reg
   const int N = p.N, D = p.D;
@@ -80,28 +237,19 @@ __global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
   const double noise = th[D + 1];
   const double jit_in = p.jitter_in ? p.jitter_in[task] : 0.0;
   double* Lg = (p.flags & SCAML_FIT_STORE_L) ? p.L + (size_t)task * N * N : nullptr;
+  const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
 
-  // tile coordinates of this wave's slots (wave-uniform)
-  int ti[SLOTS], tj[SLOTS];
+  // tile coordinates of this wave's slots (wave-uniform): tij = ti | tj << 8, -1 when unused
+  int tij[20];
 #pragma unroll
-  for (int s = 0; s < SLOTS; ++s) {
-    int t = s * W + wave;
+  for (int s = 0; s < 20; ++s) {
+    int t = s * WU + wave;
     int j = 0, off = 0;
     while (j < NB - 1 && off + (NB - j) <= t) { off += NB - j; ++j; }
-    bool valid = t < NT;
-    tj[s] = valid ? j : -1;
-    ti[s] = valid ? j + (t - off) : -1;
+    tij[s] = (s < SLOTS && t < NT && !is_panel) ? ((j + (t - off)) | (j << 8)) : -1;
   }
 
-  // strict upper triangle of L := 0 (optional), fire-and-forget
-  if (Lg && (p.flags & SCAML_FIT_ZERO_UPPER)) {
-    for (int e = tid; e < n * n; e += NTHREADS) {
-      int r = e / n, c = e - r * n;
-      if (c > r) Lg[(size_t)r * N + c] = 0.0;
-    }
-  }
-
-  d4_t acc[SLOTS];
+  STAMP_DECL;
   int fail = 0;
   double jitter = 0.0;
   const int max_attempts = (p.flags & SCAML_FIT_NO_RETRY) ? 1 : 4;
@@ -114,157 +262,201 @@ __global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
     if (tid == 0) flagp[0] = 0;
     __syncthreads();
     // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
-    for (int e = tid; e < NP * D; e += NTHREADS) {
-      int r = e / D, d = e - r * D;
-      double v = r < n ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
-      xsT[d * NP + r] = v;
+    for (int r = tid; r < NP; r += NTHREADS) {
+      const bool in = r < n;
+      for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+      ytil[r] = in ? yg[r] : 0.0;
     }
-    for (int r = tid; r < NP; r += NTHREADS) ytil[r] = r < n ? yg[r] : 0.0;
     __syncthreads();
+    STAMP(0);
 
-    // ---- kernel matrix straight into the accumulator tiles
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-      if (ti[s] >= 0) {
-        const int col = 16 * tj[s] + lc;
-        const int row0 = 16 * ti[s] + lq;
-        double d2[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int d = 0; d < D; ++d) {
-          const double* xr = xsT + d * NP;
-          const double xc = xr[col];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            double df = xr[row0 + 4 * g] - xc;
-            d2[g] = __builtin_fma(df, df, d2[g]);
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = row0 + 4 * g;
-          double kv = os * kernel_from_sqdist<KIND>(d2[g]);
-          if (row == col) kv += diag_add;
-          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
-          acc[s][g] = kv;
-        }
-      }
+    // ---- kernel matrix straight into the accumulator tiles (update waves)
+#define KBUILD_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                             \
+    if (S < SLOTS) {                                                                               \
+      const int t = opaque_s(tij[S]);                                                              \
+      if (t >= 0) {                                                                                \
+        const int col = 16 * (t >> 8) + lc;                                                        \
+        const int row0 = 16 * (t & 0xff) + lq;                                                     \
+        double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                       \
+        for (int d = 0; d < D; ++d) {                                                              \
+          const double* xr = xsT + d * NP;                                                         \
+          const double xc = xr[col];                                                               \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
+            double df = xr[row0 + 4 * g] - xc;                                                     \
+            d2[g] = __builtin_fma(df, df, d2[g]);                                                  \
+          }                                                                                        \
+        }                                                                                          \
+        double kt[4];                                                                              \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
+          const int row = row0 + 4 * g;                                                            \
+          double kv = os * kernel_from_sqdist<KIND>(d2[g]);                                        \
+          if (row == col) kv += diag_add;                                                          \
+          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                                   \
+          kt[g] = kv;                                                                              \
+        }                                                                                          \
+        TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                      \
+      }                                                                                            \
     }
-    __syncthreads();  // xsT dead from here: region A becomes PT / LkkAll
+    if (!is_panel) { SCAML_TILE_LIST(KBUILD_SLOT) }
+#undef KBUILD_SLOT
+    __syncthreads();  // xsT dead from here: region A becomes PT / WAll
+    STAMP(1);
 
-    // ---- right-looking blocked Cholesky, panel width 16
+    // ---- prologue: column 0 to LDS, diagonal block 0 factored
     fail = 0;
-    for (int k = 0; k < NB; ++k) {
-      double* buf = PT + (k & 1) * 16 * PITCH;
-      // P1: spill panel column k (raw trailing values) to LDS, buf[c][row]
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (tj[s] == k) {
-          const int rb = 16 * ti[s] + lq;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) buf[lc * PITCH + rb + 4 * g] = acc[s][g];
+#define SPILL0_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                             \
+    if (S < SLOTS) {                                                                               \
+      const int t = opaque_s(tij[S]);                                                              \
+      if (t >= 0 && (t >> 8) == 0) {                                                               \
+        double e0, e1, e2, e3;                                                                     \
+        TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                                  \
+        double* dst = PT + (16 * (t & 0xff) + lq) * PP + lc;                                       \
+        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;                        \
+      }                                                                                            \
+    }
+    if (!is_panel) { SCAML_TILE_LIST(SPILL0_SLOT) }
+#undef SPILL0_SLOT
+    __syncthreads();
+    if (is_panel) {
+      int bad = potf2_inv_block(PT, WAll, rinv, dl, vv, ytil, 0, lane);
+      if (bad && lane == 0) flagp[0] = bad;
+    }
+    __syncthreads();
+    STAMP(2);
+    fail = flagp[0];
+
+    if (!fail) {
+      for (int k = 0; k < NB; ++k) {
+        double* buf = PT + (k & 1) * PANEL;         // panel k: diagonal block final, rows below raw
+        double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1
+        const double* Wk = WAll + k * 16 * PP;
+        if (!is_panel) {
+          // T(k): column k becomes final.  Sub-diagonal tiles: L_ik = A_ik W^T (4 MFMAs, A rows from the
+          // panel, W = L_kk^-1); the diagonal tile is read back from the panel.
+#define TRSM_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
+          if (S < SLOTS) {                                                                         \
+            const int t = opaque_s(tij[S]);                                                        \
+            if (t >= 0 && (t >> 8) == k) {                                                         \
+              const int ti = t & 0xff;                                                             \
+              if (ti == k) {                                                                       \
+                const double* prow = buf + (16 * ti + lq) * PP + lc;                               \
+                TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]); \
+              } else {                                                                             \
+                const double* pa = buf + (16 * ti + lc) * PP + lq;                                 \
+                const double* pw = Wk + lc * PP + lq;                                              \
+                TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]); \
+              }                                                                                    \
+            }                                                                                      \
+          }
+          SCAML_TILE_LIST(TRSM_SLOT)
+#undef TRSM_SLOT
+          MFMA_DRAIN();
+          // final tiles: back to the panel for everyone's operand reads, out to HBM from registers
+          // (128-byte row segments; the mirrored upper tile is written as zeros by the same lanes)
+#define FINAL_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                              \
+          if (S < SLOTS) {                                                                         \
+            const int t = opaque_s(tij[S]);                                                        \
+            if (t >= 0 && (t >> 8) == k) {                                                         \
+              const int ti = t & 0xff;                                                             \
+              double e[4];                                                                         \
+              TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);                    \
+              if (ti != k) {                                                                       \
+                double* prow = buf + (16 * ti + lq) * PP + lc;                                     \
+                prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];    \
+              }                                                                                    \
+              if (Lg) {                                                                            \
+                const int col = 16 * k + lc, mc = 16 * ti + lc;                                    \
+                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                    \
+                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;                  \
+                  if (row < n && col < n && (zero_upper || col <= row)) Lg[(size_t)row * N + col] = e[g]; \
+                  if (zero_upper && ti != k && mr < n && mc < n) Lg[(size_t)mr * N + mc] = 0.0;    \
+                }                                                                                  \
+              }                                                                                    \
+            }                                                                                      \
+          }
+          SCAML_TILE_LIST(FINAL_SLOT)
+#undef FINAL_SLOT
         }
-      }
-      __syncthreads();
-      // P2: wave 0 factors the 16x16 diagonal block (row lc per lane, replicated over lq)
-      if (wave == 0) {
-        double a[16];
+        STAMP(3);
+        __syncthreads();  // Z: panel k final in LDS
+        STAMP(4);
+        if (k + 1 == NB) break;
+        if (is_panel) {
+          // running right-hand side: y_r -= L[r, panel k] . v_k for every row below the block
+          double vk[16];
+          const double vmine = vv[16 * k + lc];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = buf[c * PITCH + 16 * k + lc];
-        double yv = ytil[16 * k + lc];
-        double my_rinv = 0.0, my_diag = 1.0, my_v = 0.0;
-        int bad = 0;
+          for (int c = 0; c < 16; ++c) vk[c] = readlane_f64(vmine, c);
+          for (int r = 16 * (k + 1) + lane; r < NP; r += 64) {
+            const double* pr = buf + r * PP;
+            double yr = ytil[r];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double dpiv = readlane_f64(a[c], c);
-          if (!(dpiv > 0.0)) {  // also catches NaN
-            if (!bad) bad = 16 * k + c + 1;
-            dpiv = 1.0;
+            for (int c = 0; c < 16; ++c) yr = __builtin_fma(-pr[c], vk[c], yr);
+            ytil[r] = yr;
           }
-          const double ri = rsqrt_pos(dpiv);
-          const double lcol = a[c] * ri;  // l_{r,c} for r > c
-          const double ldiag = sqrt_from_rinv(dpiv, ri);
-          a[c] = lc == c ? ldiag : (lc > c ? lcol : 0.0);
-          const double vc = readlane_f64(yv, c) * ri;
-          if (lc == c) { my_rinv = ri; my_diag = ldiag; my_v = vc; }
-          yv = __builtin_fma(-a[c], vc, yv);
-#pragma unroll
-          for (int j = c + 1; j < 16; ++j) {
-            const double ljc = readlane_f64(a[c], j);
-            a[j] = __builtin_fma(-a[c], ljc, a[j]);
+        } else {
+          // U1: column k+1 first: rank-16 update, then spill (raw) to the other panel buffer
+#define U1_MFMA_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
+          if (S < SLOTS) {                                                                         \
+            const int t = opaque_s(tij[S]);                                                        \
+            if (t >= 0 && (t >> 8) == k + 1) {                                                     \
+              const double* pa = buf + (16 * (t & 0xff) + lc) * PP + lq;                           \
+              const double* pb = buf + (16 * (k + 1) + lc) * PP + lq;                              \
+              TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+            }                                                                                      \
           }
+          SCAML_TILE_LIST(U1_MFMA_SLOT)
+#undef U1_MFMA_SLOT
+          MFMA_DRAIN();
+#define U1_SPILL_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
+          if (S < SLOTS) {                                                                         \
+            const int t = opaque_s(tij[S]);                                                        \
+            if (t >= 0 && (t >> 8) == k + 1) {                                                     \
+              double e0, e1, e2, e3;                                                               \
+              TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                            \
+              double* dst = nbuf + (16 * (t & 0xff) + lq) * PP + lc;                               \
+              dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;                  \
+            }                                                                                      \
+          }
+          SCAML_TILE_LIST(U1_SPILL_SLOT)
+#undef U1_SPILL_SLOT
         }
-        if (lq == 0) {
-          double* Lk = LkkAll + k * 256;
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            Lk[lc * 16 + c] = a[c];
-            buf[c * PITCH + 16 * k + lc] = a[c];
+        STAMP(5);
+        __syncthreads();  // X: column k+1 (raw) and the updated right-hand side visible to the panel wave
+        STAMP(6);
+        if (is_panel) {
+          int bad = potf2_inv_block(nbuf, WAll + (k + 1) * 16 * PP, rinv, dl, vv, ytil, k + 1, lane);
+          if (bad && lane == 0) flagp[0] = bad;
+        } else {
+          // U2: the bulk of the trailing update, overlapped with the panel wave
+#define U2_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
+          if (S < SLOTS) {                                                                         \
+            const int t = opaque_s(tij[S]);                                                        \
+            if (t >= 0 && (t >> 8) > k + 1) {                                                      \
+              const double* pa = buf + (16 * (t & 0xff) + lc) * PP + lq;                           \
+              const double* pb = buf + (16 * (t >> 8) + lc) * PP + lq;                             \
+              TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+            }                                                                                      \
           }
-          rinv[16 * k + lc] = my_rinv;
-          dl[16 * k + lc] = my_diag;
-          vv[16 * k + lc] = my_v;
+          SCAML_TILE_LIST(U2_SLOT)
+#undef U2_SLOT
+          MFMA_DRAIN();
         }
-        if (bad && lane == 0) flagp[0] = bad;
-      }
-      __syncthreads();
-      fail = flagp[0];
-      if (fail) break;
-      // P3: one thread per sub-diagonal row: x L_kk^T = a, then y_r -= x . v_k
-      {
-        const int r = 16 * (k + 1) + tid;
-        if (r < NP) {
-          double x[16];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) x[c] = buf[c * PITCH + r];
-          const double* Lk = LkkAll + k * 256;
-          const double* ri = rinv + 16 * k;
-          const double* vk = vv + 16 * k;
-          double yr = ytil[r];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            x[c] *= ri[c];
-#pragma unroll
-            for (int j = c + 1; j < 16; ++j) x[j] = __builtin_fma(-x[c], Lk[j * 16 + c], x[j]);
-            yr = __builtin_fma(-x[c], vk[c], yr);
-          }
-#pragma unroll
-          for (int c = 0; c < 16; ++c) buf[c * PITCH + r] = x[c];
-          ytil[r] = yr;
-        }
-      }
-      __syncthreads();
-      // P4: rank-16 trailing update on the matrix cores; finished tiles return to registers
-#pragma unroll
-      for (int s = 0; s < SLOTS; ++s) {
-        if (tj[s] > k) {
-          const double* pa = buf + lq * PITCH + 16 * ti[s] + lc;
-          const double* pb = buf + lq * PITCH + 16 * tj[s] + lc;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const double av = pa[4 * m * PITCH];
-            const double bv = pb[4 * m * PITCH];
-            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, bv, acc[s], 0, 0, 0);
-          }
-        } else if (tj[s] == k) {
-          const int rb = 16 * ti[s] + lq;
-          const int col = 16 * k + lc;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = rb + 4 * g;
-            double lv = buf[lc * PITCH + row];
-            if (col > row) lv = 0.0;
-            acc[s][g] = lv;
-            if (Lg && row < n && col < n && col <= row) Lg[(size_t)row * N + col] = lv;
-          }
-        }
+        STAMP(7);
+        __syncthreads();  // Y: diagonal block k+1 factored
+        STAMP(8);
+        fail = flagp[0];
+        if (fail) break;
       }
     }
     if (!fail) break;
   }
 
-  // ---- scalars: quad, logdet (wave 0), then alpha by blocked back-substitution
+  // ---- scalars: quad, logdet (panel wave), then alpha by blocked back-substitution
   __syncthreads();
+  STAMP(9);
   if (!fail) {
-    if (wave == 0) {
+    if (is_panel) {
       double q = 0.0, ld = 0.0;
       for (int r = lane; r < NP; r += 64) {
         const double v = vv[r];
@@ -287,35 +479,33 @@ __global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
       for (int r = tid; r < NP; r += NTHREADS) ww[r] = vv[r];
       __syncthreads();
       for (int k = NB - 1; k >= 0; --k) {
-        if (wave == 0) {
-          // lane m (< 16) holds column m of L_kk and w_m; solve L_kk^T a = w
-          const double* Lk = LkkAll + k * 256;
-          double colm[16];
+        if (is_panel) {
+          // alpha_k = L_kk^-T w_k = W^T w_k: lane m accumulates sum_c W[c][m] w_c
+          const double* Wk = WAll + k * 16 * PP;
+          double a = 0.0;
 #pragma unroll
-          for (int c = 0; c < 16; ++c) colm[c] = Lk[c * 16 + lc];
-          double wreg = ww[16 * k + lc];
-          const double myri = rinv[16 * k + lc];
-          double res = 0.0;
-#pragma unroll
-          for (int c = 15; c >= 0; --c) {
-            const double ac = readlane_f64(wreg * myri, c);
-            if (lc == c) res = ac;
-            wreg = __builtin_fma(-colm[c], ac, wreg);  // only lanes m < c are used later
-          }
-          if (lq == 0) ww[16 * k + lc] = res;
+          for (int c = 0; c < 16; ++c) a = __builtin_fma(Wk[c * PP + lc], ww[16 * k + c], a);
+          if (lq == 0) ww[16 * k + lc] = a;
         }
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-          if (ti[s] == k && tj[s] < k) {
-            double part = 0.0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) part = __builtin_fma(acc[s][g], ww[16 * k + lq + 4 * g], part);
-            part += __shfl_xor(part, 16);
-            part += __shfl_xor(part, 32);
-            if (lq == 0) ww[16 * tj[s] + lc] -= part;
-          }
+#define BACKSUB_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
+        if (S < SLOTS) {                                                                           \
+          const int t = opaque_s(tij[S]);                                                          \
+          if (t >= 0 && (t & 0xff) == k && (t >> 8) < k) {                                         \
+            double e0, e1, e2, e3;                                                                 \
+            TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                              \
+            const double* wk = ww + 16 * k + lq;                                                   \
+            double part = e0 * wk[0];                                                              \
+            part = __builtin_fma(e1, wk[4], part);                                                 \
+            part = __builtin_fma(e2, wk[8], part);                                                 \
+            part = __builtin_fma(e3, wk[12], part);                                                \
+            part += __shfl_xor(part, 16);                                                          \
+            part += __shfl_xor(part, 32);                                                          \
+            if (lq == 0) ww[16 * (t >> 8) + lc] -= part;                                           \
+          }                                                                                        \
         }
+        if (!is_panel) { SCAML_TILE_LIST(BACKSUB_SLOT) }
+#undef BACKSUB_SLOT
         __syncthreads();
       }
       for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = ww[r];
@@ -330,24 +520,30 @@ __global__ __launch_bounds__(W * 64) void gp_fit_fused_kernel(FitParams p) {
     p.info[task] = fail;
     if (p.jitter_used) p.jitter_used[task] = jitter;
   }
+  STAMP(10);
+  STAMP_FLUSH(task);
 }
 
-template <int NB, int W>
+template <int NB>
 static size_t fit_lds_bytes(int D) {
-  const int NP = NB * 16, PITCH = NP + 16;
-  size_t regionA = (size_t)2 * 16 * PITCH + NB * 256;
+  const int NP = NB * 16;
+  size_t regionA = (size_t)2 * NP * scaml::PP + NB * 16 * scaml::PP;
   if ((size_t)D * NP > regionA) regionA = (size_t)D * NP;
   return (regionA + 5 * NP + D + (D & 1) + 2) * sizeof(double);
 }
 
-template <int NB, int W>
+template <int NB, int WU>
 static int launch_fit(const FitParams& p, int kind, hipStream_t stream) {
-  const size_t lds = fit_lds_bytes<NB, W>(p.D);
+  const size_t lds = fit_lds_bytes<NB>(p.D);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
-  auto kern = kind == SCAML_KIND_RBF ? gp_fit_fused_kernel<NB, W, 0> : gp_fit_fused_kernel<NB, W, 1>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return SCAML_E_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3(p.T), dim3(W * 64), lds, stream, p);
+  auto kern = kind == SCAML_KIND_RBF ? gp_fit_fused_kernel<NB, WU, 0> : gp_fit_fused_kernel<NB, WU, 1>;
+  static int configured[2] = {0, 0};  // LDS limit already raised to this many bytes, per kind
+  if (configured[kind] < (int)lds) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return SCAML_E_LAUNCH;
+    configured[kind] = 160 * 1024;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.T), dim3((WU + 1) * 64), lds, stream, p);
   return hipGetLastError() == hipSuccess ? SCAML_OK : SCAML_E_LAUNCH;
 }
 
@@ -357,7 +553,13 @@ static thread_local char g_last_error[256] = "";
 
 extern "C" {
 
-int scaml_version(void) { return 100; }  // 0.1.0
+#ifdef SCAML_STAMPS
+int scaml_debug_set_stamp_buffer(long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+int scaml_version(void) { return 200; }  // 0.2.0
 const char* scaml_last_error(void) { return g_last_error; }
 int scaml_fit_max_n(void) { return 256; }
 
@@ -385,9 +587,9 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (N <= 32) rc = scaml::launch_fit<2, 1>(p, kind, s);
-  else if (N <= 64) rc = scaml::launch_fit<4, 2>(p, kind, s);
-  else if (N <= 128) rc = scaml::launch_fit<8, 4>(p, kind, s);
-  else rc = scaml::launch_fit<16, 8>(p, kind, s);
+  else if (N <= 64) rc = scaml::launch_fit<4, 1>(p, kind, s);
+  else if (N <= 128) rc = scaml::launch_fit<8, 3>(p, kind, s);
+  else rc = scaml::launch_fit<16, 7>(p, kind, s);
   if (rc == SCAML_E_LAUNCH) {
     hipError_t e = hipGetLastError();
     snprintf(g_last_error, sizeof(g_last_error), "%s", hipGetErrorString(e));

@@ -8,7 +8,14 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int32, c_uint, c_void_p, POINTER
+from ctypes import c_char_p, c_int, c_uint, c_void_p
+
+# torch must be imported BEFORE the library is loaded: torch ships its own libamdhip64.so.7 and
+# libscaml_hip.so links against the same SONAME, so whichever loads first serves both.  Device
+# pointers and streams handed across the C ABI come from torch's runtime instance; loading the
+# system copy first would give this library a second, unrelated HIP runtime ("no ROCm-capable
+# device is detected" at the first launch).
+import torch  # noqa: F401  (side effect: HIP runtime loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libscaml_hip.so")

@@ -49,12 +49,14 @@ def gp_fit_fused(
     zero_upper: bool = True,
     retry: bool = True,
     want_alpha: bool = True,
+    out: Optional[Dict[str, torch.Tensor]] = None,
 ) -> Dict[str, torch.Tensor]:
     """K + noise, jittered Cholesky, alpha, quad, logdet, MLL for a stack of tasks.
 
     X (T, N, D), y (T, N), theta (T, D+2) = [lengthscales, outputscale, noise] (constrained).
     Returns dict(L, alpha, quad, logdet, mll, info, jitter); ``L`` is None when store_L=False.
-    One launch of ``scaml_gp_fit_fused_f64`` (include/scaml_gp.h).
+    One launch of ``scaml_gp_fit_fused_f64`` (include/scaml_gp.h).  ``out`` may be the dict a
+    previous call returned for the same shapes/flags: its tensors are reused (no allocation).
     """
     if X.dim() != 3:
         raise ValueError("X must be (T, N, D)")
@@ -68,13 +70,18 @@ def gp_fit_fused(
         jitter = _check(jitter, "jitter", (T,))
     dev = X.device
     with torch.cuda.device(dev):
-        L = torch.empty((T, N, N), dtype=torch.float64, device=dev) if store_L else None
-        alpha = torch.empty((T, N), dtype=torch.float64, device=dev) if want_alpha else None
-        quad = torch.empty((T,), dtype=torch.float64, device=dev)
-        logdet = torch.empty((T,), dtype=torch.float64, device=dev)
-        mll = torch.empty((T,), dtype=torch.float64, device=dev)
-        info = torch.empty((T,), dtype=torch.int32, device=dev)
-        jit_used = torch.empty((T,), dtype=torch.float64, device=dev)
+        if out is not None:
+            L, alpha, quad, logdet, mll, info, jit_used = (out[k] for k in ("L", "alpha", "quad", "logdet", "mll", "info", "jitter"))
+            if (L is None) == store_L or (alpha is None) == want_alpha or quad.shape != (T,) or (store_L and L.shape != (T, N, N)):
+                raise ValueError("out= does not match this call's shapes/flags")
+        else:
+            L = torch.empty((T, N, N), dtype=torch.float64, device=dev) if store_L else None
+            alpha = torch.empty((T, N), dtype=torch.float64, device=dev) if want_alpha else None
+            quad = torch.empty((T,), dtype=torch.float64, device=dev)
+            logdet = torch.empty((T,), dtype=torch.float64, device=dev)
+            mll = torch.empty((T,), dtype=torch.float64, device=dev)
+            info = torch.empty((T,), dtype=torch.int32, device=dev)
+            jit_used = torch.empty((T,), dtype=torch.float64, device=dev)
         if n_points is not None and want_alpha:
             alpha.zero_()
         flags = 0
