@@ -29,6 +29,7 @@
 // linear_operator's psd_safe_cholesky does on the host.
 #include "scaml_common.hpp"
 #include "../../include/scaml_gp.h"
+#include "gp_fit_params.h"
 
 #ifdef SCAML_STAMPS
 // Diagnostic build only (tools/build_stamps.sh): thread 0 of every workgroup accumulates
@@ -45,22 +46,7 @@ __device__ long long* g_stamp_buf = nullptr;
 
 namespace scaml {
 
-struct FitParams {
-  const double* X;
-  const double* y;
-  const double* theta;
-  const int32_t* n_points;
-  const double* jitter_in;
-  double* L;
-  double* alpha;
-  double* quad;
-  double* logdet;
-  double* mll;
-  int32_t* info;
-  double* jitter_used;
-  int T, N, D;
-  unsigned flags;
-};
+
 
 // LDS panel layout: PANEL[row * PP + c], PP = 17 doubles.  With this pitch the MFMA operand reads
 // (lane -> row 16t + (lane & 15), column 4m + (lane >> 4)), the C/D-layout tile spills/reloads
@@ -78,9 +64,11 @@ __device__ __forceinline__ int opaque_s(int v) {
 // operand position on lane group c & 3), applies the rank-1 update with ONE MFMA and forms the
 // next pivot ahead of it on the VALU, so the 64-cycle MFMA latency is off the pivot chain.  A
 // second accumulator R (initially I) receives the same row operations and ends as W = L_kk^-1.
-// Outputs: panel rows <- L_kk (zero above the diagonal), Wk[c * PP + j] = W[c][j], rinv, dl, vv.
+// Lanes outside the active group store to a per-lane trash slot instead of being masked off
+// (no exec juggling in the 16-step chain).
+// Outputs: panel rows <- L_kk (zero above the diagonal), Wk[c * PP + j] = W[c][j], vv.
 // Returns 0 or the 1-based global index of the first non-positive / out-of-range pivot.
-__device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double* rinv, double* dl, double* vv,
+__device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double* vv, double* trash,
                                                const double* ytil, int k, int lane) {
   const int lc = lane & 15, lq = lane >> 4;
   d4_t a, R;
@@ -89,6 +77,10 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
     a[g] = panel[(16 * k + lq + 4 * g) * PP + lc];
     R[g] = (lc == lq + 4 * g) ? 1.0 : 0.0;
   }
+  // LDS element offsets relative to `panel` (the trash slot is addressed through the same base)
+  const int off_trash = (int)(trash - panel) + lane;
+  const int off_prow = (16 * k + lc) * PP;    // + c   -> L[lc][c]
+  const int off_w = (int)(Wk - panel) + lc;   // + c*PP -> W[c][lc]
   int bad = 0;
   double dpiv = readlane_f64(a[0], 0);
 #pragma unroll
@@ -100,24 +92,19 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
     }
     const double ri = rsqrt_seeded(dpiv);
     const bool mine = lq == g;
-    const double lcol = (mine && lc >= c) ? a[rg] * ri : 0.0;  // L[lc][c]
-    const double wrow = mine ? R[rg] * ri : 0.0;               // W[c][lc]
+    const bool low = (unsigned)(lane - (16 * g + c)) < (unsigned)(16 - c);  // mine && lc >= c
+    const double lcol = low ? a[rg] * ri : 0.0;   // L[lc][c]
+    const double wrow = mine ? R[rg] * ri : 0.0;  // W[c][lc]
     if (c < 15) {
       const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
       const double lnext = readlane_f64(lcol, 16 * g + c + 1);
       const double anext = readlane_f64(a[rg1], 16 * g1 + c + 1);
       dpiv = __builtin_fma(-lnext, lnext, anext);
-      a = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcol, lcol, a, 0, 0, 0);
-      R = __builtin_amdgcn_mfma_f64_16x16x4f64(-lcol, wrow, R, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
     }
-    if (mine) {
-      panel[(16 * k + lc) * PP + c] = lcol;
-      Wk[c * PP + lc] = wrow;
-    }
-    if (lane == 16 * g + c) {
-      rinv[16 * k + c] = ri;
-      dl[16 * k + c] = lcol;
-    }
+    panel[mine ? off_prow + c : off_trash] = lcol;
+    panel[mine ? off_w + c * PP : off_trash] = wrow;
   }
   // v_k = W y_k (row lc of W per lane; lane groups replicate)
   double v = 0.0;
@@ -196,9 +183,20 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
 
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
 
+// switch-dispatch of one runtime slot index onto the code for the matching physical tile
+#define SCAML_CASE_(S, r0, r1, r2, r3, r4, r5, r6, r7) \
+  case S:                                              \
+    if (S < SLOTS) { SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) } \
+    break;
+#define SCAML_DISPATCH(s) switch (s) { SCAML_TILE_LIST(SCAML_CASE_) default: break; }
+
+// One factorisation attempt with a given diagonal jitter, start to finish (kernel matrix, panel
+// loop, scalars, alpha).  Returns 0 on success or the 1-based index of the failing pivot.
+// The kernel inlines this once for the first attempt (straight-line: nothing loop-invariant can be
+// hoisted out of the kernel-matrix build and stay live across the panel loop) and calls the
+// out-of-line copy below for the rare jitter retries.
 template <int NB, int WU, int KIND>
-__global__ __launch_bounds__((WU + 1) * 64) __attribute__((amdgpu_num_vgpr(96)))
-void gp_fit_fused_kernel(FitParams p) {
+__device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double jitter) {
   constexpr int NP = NB * 16;                 // padded matrix order
   constexpr int NT = NB * (NB + 1) / 2;       // lower-triangular tiles
   constexpr int SLOTS = (NT + WU - 1) / WU;   // tiles per update wave
@@ -216,8 +214,9 @@ void gp_fit_fused_kernel(FitParams p) {
   double* vv = ytil + NP;         // [NP] v = L^-1 y
   double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
   double* dl = ww + NP;           // [NP] diag(L)
-  double* rinv = dl + NP;         // [NP] 1 / diag(L)
-  double* invl = rinv + NP;       // [D]  1 / lengthscale
+  double* trash = dl + NP;        // [64] per-lane dump slot of the panel wave
+  double* exptab = trash + 64;    // [64] 2^(j/64) for exp_neg
+  double* invl = exptab + 64;     // [D]  1 / lengthscale
   int* flagp = (int*)(invl + p.D + (p.D & 1));  // [2] fail index
 
   const int task = blockIdx.x;
@@ -238,28 +237,22 @@ void gp_fit_fused_kernel(FitParams p) {
   const double jit_in = p.jitter_in ? p.jitter_in[task] : 0.0;
   double* Lg = (p.flags & SCAML_FIT_STORE_L) ? p.L + (size_t)task * N * N : nullptr;
   const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
+  const int lane_idx = lq * N + lc;  // element offset of this lane inside a 16x16 tile of L (row-major, ld = N)
 
-  // tile coordinates of this wave's slots (wave-uniform): tij = ti | tj << 8, -1 when unused
-  int tij[20];
-#pragma unroll
-  for (int s = 0; s < 20; ++s) {
-    int t = s * WU + wave;
-    int j = 0, off = 0;
-    while (j < NB - 1 && off + (NB - j) <= t) { off += NB - j; ++j; }
-    tij[s] = (s < SLOTS && t < NT && !is_panel) ? ((j + (t - off)) | (j << 8)) : -1;
-  }
+  // Tiles in column-major order over the lower triangle: column j starts at tile off(j); this wave
+  // owns tiles t = s * WU + wave (slot s), so its tiles of column j are the contiguous slots
+  // [slo(j), slo(j+1)) and everything right of column j is the suffix starting at slo(j+1).
+  auto off = [](int j) { return j * NB - j * (j - 1) / 2; };
+  auto slo = [&](int j) { const int o = off(j) - wave; return o <= 0 ? 0 : (o + WU - 1) / WU; };
 
   STAMP_DECL;
   int fail = 0;
-  double jitter = 0.0;
-  const int max_attempts = (p.flags & SCAML_FIT_NO_RETRY) ? 1 : 4;
-
-  for (int attempt = 0; attempt < max_attempts; ++attempt) {
-    jitter = attempt == 0 ? 0.0 : (attempt == 1 ? 1e-8 : (attempt == 2 ? 1e-7 : 1e-6));
+  {
     const double diag_add = noise + jitter + jit_in;
     __syncthreads();  // previous attempt done with region A
     if (tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
+    exp2_table_init(exptab, tid);
     __syncthreads();
     // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
     for (int r = tid; r < NP; r += NTHREADS) {
@@ -271,54 +264,59 @@ void gp_fit_fused_kernel(FitParams p) {
     STAMP(0);
 
     // ---- kernel matrix straight into the accumulator tiles (update waves)
-#define KBUILD_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                             \
-    if (S < SLOTS) {                                                                               \
-      const int t = opaque_s(tij[S]);                                                              \
-      if (t >= 0) {                                                                                \
-        const int col = 16 * (t >> 8) + lc;                                                        \
-        const int row0 = 16 * (t & 0xff) + lq;                                                     \
-        double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                       \
-        for (int d = 0; d < D; ++d) {                                                              \
-          const double* xr = xsT + d * NP;                                                         \
-          const double xc = xr[col];                                                               \
-          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
-            double df = xr[row0 + 4 * g] - xc;                                                     \
-            d2[g] = __builtin_fma(df, df, d2[g]);                                                  \
+    if (!is_panel) {
+      int kj = 0, kr = wave;  // column / row-in-column of the current slot's tile
+#define SCAML_KBUILD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
+      if (S < SLOTS) {                                                                             \
+        while (kj < NB && kr >= NB - kj) { kr -= NB - kj; ++kj; }                                  \
+        if (kj < NB) {                                                                             \
+          const int col = 16 * kj + lc;                                                            \
+          const int row0 = 16 * (kj + kr) + lq;                                                    \
+          double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                     \
+          _Pragma("unroll 2") for (int d = 0; d < D; ++d) {                                        \
+            const double* xr = xsT + d * NP;                                                       \
+            const double xc = xr[col];                                                             \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+              double df = xr[row0 + 4 * g] - xc;                                                   \
+              d2[g] = __builtin_fma(df, df, d2[g]);                                                \
+            }                                                                                      \
           }                                                                                        \
+          double kt[4];                                                                            \
+          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
+            const int row = row0 + 4 * g;                                                          \
+            double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);                                      \
+            if (row == col) kv += diag_add;                                                        \
+            if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                                 \
+            kt[g] = kv;                                                                            \
+          }                                                                                        \
+          TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                    \
+          kr += WU;                                                                                \
         }                                                                                          \
-        double kt[4];                                                                              \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
-          const int row = row0 + 4 * g;                                                            \
-          double kv = os * kernel_from_sqdist<KIND>(d2[g]);                                        \
-          if (row == col) kv += diag_add;                                                          \
-          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                                   \
-          kt[g] = kv;                                                                              \
-        }                                                                                          \
-        TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                      \
-      }                                                                                            \
+      }
+      SCAML_TILE_LIST(SCAML_KBUILD_)
+#undef SCAML_KBUILD_
     }
-    if (!is_panel) { SCAML_TILE_LIST(KBUILD_SLOT) }
-#undef KBUILD_SLOT
     __syncthreads();  // xsT dead from here: region A becomes PT / WAll
     STAMP(1);
 
     // ---- prologue: column 0 to LDS, diagonal block 0 factored
     fail = 0;
-#define SPILL0_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                             \
-    if (S < SLOTS) {                                                                               \
-      const int t = opaque_s(tij[S]);                                                              \
-      if (t >= 0 && (t >> 8) == 0) {                                                               \
+    if (!is_panel) {
+      const int s1 = slo(1);
+      for (int s = 0; s < s1; ++s) {
+        const int ti = s * WU + wave;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
         double e0, e1, e2, e3;                                                                     \
         TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                                  \
-        double* dst = PT + (16 * (t & 0xff) + lq) * PP + lc;                                       \
-        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;                        \
-      }                                                                                            \
+        double* dst = PT + (16 * ti + lq) * PP + lc;                                               \
+        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
+        SCAML_DISPATCH(s)
+#undef SCAML_BODY
+      }
     }
-    if (!is_panel) { SCAML_TILE_LIST(SPILL0_SLOT) }
-#undef SPILL0_SLOT
     __syncthreads();
     if (is_panel) {
-      int bad = potf2_inv_block(PT, WAll, rinv, dl, vv, ytil, 0, lane);
+      int bad = potf2_inv_block(PT, WAll, vv, trash, ytil, 0, lane);
       if (bad && lane == 0) flagp[0] = bad;
     }
     __syncthreads();
@@ -331,51 +329,60 @@ void gp_fit_fused_kernel(FitParams p) {
         double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1
         const double* Wk = WAll + k * 16 * PP;
         if (!is_panel) {
+          const int sa = slo(k), sb = slo(k + 1), offk = off(k);
           // T(k): column k becomes final.  Sub-diagonal tiles: L_ik = A_ik W^T (4 MFMAs, A rows from the
           // panel, W = L_kk^-1); the diagonal tile is read back from the panel.
-#define TRSM_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
-          if (S < SLOTS) {                                                                         \
-            const int t = opaque_s(tij[S]);                                                        \
-            if (t >= 0 && (t >> 8) == k) {                                                         \
-              const int ti = t & 0xff;                                                             \
-              if (ti == k) {                                                                       \
-                const double* prow = buf + (16 * ti + lq) * PP + lc;                               \
-                TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]); \
-              } else {                                                                             \
-                const double* pa = buf + (16 * ti + lc) * PP + lq;                                 \
-                const double* pw = Wk + lc * PP + lq;                                              \
-                TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]); \
-              }                                                                                    \
-            }                                                                                      \
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + (s * WU + wave - offk);
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
+            if (ti == k) {                                                                         \
+              const double* prow = buf + (16 * ti + lq) * PP + lc;                                 \
+              TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]); \
+            } else {                                                                               \
+              const double* pa = buf + (16 * ti + lc) * PP + lq;                                   \
+              const double* pw = Wk + lc * PP + lq;                                                \
+              TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]); \
+            }
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
           }
-          SCAML_TILE_LIST(TRSM_SLOT)
-#undef TRSM_SLOT
           MFMA_DRAIN();
           // final tiles: back to the panel for everyone's operand reads, out to HBM from registers
           // (128-byte row segments; the mirrored upper tile is written as zeros by the same lanes)
-#define FINAL_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                              \
-          if (S < SLOTS) {                                                                         \
-            const int t = opaque_s(tij[S]);                                                        \
-            if (t >= 0 && (t >> 8) == k) {                                                         \
-              const int ti = t & 0xff;                                                             \
-              double e[4];                                                                         \
-              TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);                    \
-              if (ti != k) {                                                                       \
-                double* prow = buf + (16 * ti + lq) * PP + lc;                                     \
-                prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];    \
-              }                                                                                    \
-              if (Lg) {                                                                            \
-                const int col = 16 * k + lc, mc = 16 * ti + lc;                                    \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                    \
-                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;                  \
-                  if (row < n && col < n && (zero_upper || col <= row)) Lg[(size_t)row * N + col] = e[g]; \
-                  if (zero_upper && ti != k && mr < n && mc < n) Lg[(size_t)mr * N + mc] = 0.0;    \
-                }                                                                                  \
-              }                                                                                    \
-            }                                                                                      \
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + (s * WU + wave - offk);
+            double e[4];
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
+            if (ti != k) {
+              double* prow = buf + (16 * ti + lq) * PP + lc;
+              prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];
+            } else {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                if (lc == lq + 4 * g) dl[16 * k + lc] = e[g];
+            }
+            if (Lg) {
+              double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
+              double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
+              if (16 * ti + 16 <= n && ti != k) {                   // interior tile: no per-lane bounds
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                  if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+                }
+              } else {
+                const int col = 16 * k + lc, mc = 16 * ti + lc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;
+                  if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                  if (zero_upper && ti != k && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+                }
+              }
+            }
           }
-          SCAML_TILE_LIST(FINAL_SLOT)
-#undef FINAL_SLOT
         }
         STAMP(3);
         __syncthreads();  // Z: panel k final in LDS
@@ -396,50 +403,51 @@ void gp_fit_fused_kernel(FitParams p) {
           }
         } else {
           // U1: column k+1 first: rank-16 update, then spill (raw) to the other panel buffer
-#define U1_MFMA_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
-          if (S < SLOTS) {                                                                         \
-            const int t = opaque_s(tij[S]);                                                        \
-            if (t >= 0 && (t >> 8) == k + 1) {                                                     \
-              const double* pa = buf + (16 * (t & 0xff) + lc) * PP + lq;                           \
-              const double* pb = buf + (16 * (k + 1) + lc) * PP + lq;                              \
-              TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
-            }                                                                                      \
+          const int sa = slo(k + 1), sb = slo(k + 2), offk1 = off(k + 1);
+          const double* pb = buf + (16 * (k + 1) + lc) * PP + lq;
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + 1 + (s * WU + wave - offk1);
+            const double* pa = buf + (16 * ti + lc) * PP + lq;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) \
+            TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]);
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
           }
-          SCAML_TILE_LIST(U1_MFMA_SLOT)
-#undef U1_MFMA_SLOT
           MFMA_DRAIN();
-#define U1_SPILL_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
-          if (S < SLOTS) {                                                                         \
-            const int t = opaque_s(tij[S]);                                                        \
-            if (t >= 0 && (t >> 8) == k + 1) {                                                     \
-              double e0, e1, e2, e3;                                                               \
-              TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                            \
-              double* dst = nbuf + (16 * (t & 0xff) + lq) * PP + lc;                               \
-              dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;                  \
-            }                                                                                      \
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + 1 + (s * WU + wave - offk1);
+            double e0, e1, e2, e3;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
+            double* dst = nbuf + (16 * ti + lq) * PP + lc;
+            dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
           }
-          SCAML_TILE_LIST(U1_SPILL_SLOT)
-#undef U1_SPILL_SLOT
         }
         STAMP(5);
         __syncthreads();  // X: column k+1 (raw) and the updated right-hand side visible to the panel wave
         STAMP(6);
         if (is_panel) {
-          int bad = potf2_inv_block(nbuf, WAll + (k + 1) * 16 * PP, rinv, dl, vv, ytil, k + 1, lane);
+          int bad = potf2_inv_block(nbuf, WAll + (k + 1) * 16 * PP, vv, trash, ytil, k + 1, lane);
           if (bad && lane == 0) flagp[0] = bad;
         } else {
-          // U2: the bulk of the trailing update, overlapped with the panel wave
-#define U2_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
-          if (S < SLOTS) {                                                                         \
-            const int t = opaque_s(tij[S]);                                                        \
-            if (t >= 0 && (t >> 8) > k + 1) {                                                      \
-              const double* pa = buf + (16 * (t & 0xff) + lc) * PP + lq;                           \
-              const double* pb = buf + (16 * (t >> 8) + lc) * PP + lq;                             \
-              TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
-            }                                                                                      \
-          }
-          SCAML_TILE_LIST(U2_SLOT)
-#undef U2_SLOT
+          // U2: the bulk of the trailing update, overlapped with the panel wave: every slot from
+          // slo(k+2) on, entered through one switch and then falling through slot after slot
+          const int s0 = slo(k + 2);
+          int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
+#define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
+          case S:                                                                                  \
+            if (S < SLOTS) {                                                                       \
+              while (uj < NB && ur >= NB - uj) { ur -= NB - uj; ++uj; }                            \
+              if (uj < NB) {                                                                       \
+                const double* pa = buf + (16 * (uj + ur) + lc) * PP + lq;                          \
+                const double* pb = buf + (16 * uj + lc) * PP + lq;                                 \
+                TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+                ur += WU;                                                                          \
+              }                                                                                    \
+            }
+          switch (s0) { SCAML_TILE_LIST(SCAML_U2_) default: break; }
+#undef SCAML_U2_
           MFMA_DRAIN();
         }
         STAMP(7);
@@ -449,7 +457,6 @@ void gp_fit_fused_kernel(FitParams p) {
         if (fail) break;
       }
     }
-    if (!fail) break;
   }
 
   // ---- scalars: quad, logdet (panel wave), then alpha by blocked back-substitution
@@ -488,113 +495,75 @@ void gp_fit_fused_kernel(FitParams p) {
           if (lq == 0) ww[16 * k + lc] = a;
         }
         __syncthreads();
-#define BACKSUB_SLOT(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
-        if (S < SLOTS) {                                                                           \
-          const int t = opaque_s(tij[S]);                                                          \
-          if (t >= 0 && (t & 0xff) == k && (t >> 8) < k) {                                         \
-            double e0, e1, e2, e3;                                                                 \
-            TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                              \
-            const double* wk = ww + 16 * k + lq;                                                   \
-            double part = e0 * wk[0];                                                              \
-            part = __builtin_fma(e1, wk[4], part);                                                 \
-            part = __builtin_fma(e2, wk[8], part);                                                 \
-            part = __builtin_fma(e3, wk[12], part);                                                \
-            part += __shfl_xor(part, 16);                                                          \
-            part += __shfl_xor(part, 32);                                                          \
-            if (lq == 0) ww[16 * (t >> 8) + lc] -= part;                                           \
-          }                                                                                        \
+        if (!is_panel) {
+          // w_j -= L_kj^T alpha_k for the tiles (k, j), j < k, this wave holds
+          const double* wk = ww + 16 * k + lq;
+          for (int j = 0; j < k; ++j) {
+            const int t = off(j) + (k - j);
+            if (t % WU == wave) {
+              const int s = t / WU;
+              double e0, e1, e2, e3;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
+              SCAML_DISPATCH(s)
+#undef SCAML_BODY
+              double part = e0 * wk[0];
+              part = __builtin_fma(e1, wk[4], part);
+              part = __builtin_fma(e2, wk[8], part);
+              part = __builtin_fma(e3, wk[12], part);
+              part += __shfl_xor(part, 16);
+              part += __shfl_xor(part, 32);
+              if (lq == 0) ww[16 * j + lc] -= part;
+            }
+          }
         }
-        if (!is_panel) { SCAML_TILE_LIST(BACKSUB_SLOT) }
-#undef BACKSUB_SLOT
         __syncthreads();
       }
       for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = ww[r];
     }
-  } else if (tid == 0) {
-    const double nan = __builtin_nan("");
-    if (p.quad) p.quad[task] = nan;
-    if (p.logdet) p.logdet[task] = nan;
-    if (p.mll) p.mll[task] = nan;
-  }
-  if (tid == 0) {
-    p.info[task] = fail;
-    if (p.jitter_used) p.jitter_used[task] = jitter;
   }
   STAMP(10);
   STAMP_FLUSH(task);
+  return fail;
 }
 
-template <int NB>
-static size_t fit_lds_bytes(int D) {
-  const int NP = NB * 16;
-  size_t regionA = (size_t)2 * NP * scaml::PP + NB * 16 * scaml::PP;
-  if ((size_t)D * NP > regionA) regionA = (size_t)D * NP;
-  return (regionA + 5 * NP + D + (D & 1) + 2) * sizeof(double);
+template <int NB, int WU, int KIND>
+__device__ __noinline__ int gp_fit_retry(const FitParams& p, const double jitter) {
+  return gp_fit_attempt<NB, WU, KIND>(p, jitter);
 }
 
-template <int NB, int WU>
-static int launch_fit(const FitParams& p, int kind, hipStream_t stream) {
-  const size_t lds = fit_lds_bytes<NB>(p.D);
-  if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
-  auto kern = kind == SCAML_KIND_RBF ? gp_fit_fused_kernel<NB, WU, 0> : gp_fit_fused_kernel<NB, WU, 1>;
-  static int configured[2] = {0, 0};  // LDS limit already raised to this many bytes, per kind
-  if (configured[kind] < (int)lds) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return SCAML_E_LAUNCH;
-    configured[kind] = 160 * 1024;
+template <int NB, int WU, int KIND>
+__global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p) {
+  // jitter escalation of linear_operator's psd_safe_cholesky, per task, without leaving the GPU
+  double jitter = 0.0;
+  int fail = gp_fit_attempt<NB, WU, KIND>(p, 0.0);
+  if (fail && !(p.flags & SCAML_FIT_NO_RETRY)) {
+    const FitParams pc = p;  // only this cold copy has its address taken; `p` stays in the kernarg segment
+    for (int attempt = 1; attempt < 4 && fail; ++attempt) {
+      jitter = attempt == 1 ? 1e-8 : (attempt == 2 ? 1e-7 : 1e-6);
+      fail = gp_fit_retry<NB, WU, KIND>(pc, jitter);
+    }
   }
-  hipLaunchKernelGGL(kern, dim3(p.T), dim3((WU + 1) * 64), lds, stream, p);
-  return hipGetLastError() == hipSuccess ? SCAML_OK : SCAML_E_LAUNCH;
+  if (threadIdx.x == 0) {
+    const int task = blockIdx.x;
+    if (fail) {
+      const double nan = __builtin_nan("");
+      if (p.quad) p.quad[task] = nan;
+      if (p.logdet) p.logdet[task] = nan;
+      if (p.mll) p.mll[task] = nan;
+    }
+    p.info[task] = fail;
+    if (p.jitter_used) p.jitter_used[task] = jitter;
+  }
 }
 
 }  // namespace scaml
 
-static thread_local char g_last_error[256] = "";
-
-extern "C" {
-
-#ifdef SCAML_STAMPS
-int scaml_debug_set_stamp_buffer(long long* buf) {
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
-}
-#endif
-
-int scaml_version(void) { return 200; }  // 0.2.0
-const char* scaml_last_error(void) { return g_last_error; }
-int scaml_fit_max_n(void) { return 256; }
-
-int scaml_fit_max_d(int N) {
-  // largest D whose staged point stack fits the 160 KiB LDS next to the vectors
-  int np = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
-  int budget = 160 * 1024 / 8 - 5 * np - 4;
-  int d = budget / (np + 1);
-  return d > 1024 ? 1024 : d;
-}
-
-int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta,
-                           const int32_t* n_points, const double* jitter_in,
-                           int T, int N, int D, int kind,
-                           double* L, double* alpha, double* quad, double* logdet, double* mll,
-                           int32_t* info, double* jitter_used, unsigned flags, void* stream) {
-  if (T < 0 || N < 1 || D < 1) return SCAML_E_BADARG;
-  if (!X || !y || !theta || !info) return SCAML_E_BADARG;
-  if ((flags & SCAML_FIT_STORE_L) && !L) return SCAML_E_BADARG;
-  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
-  if (N > scaml_fit_max_n()) return SCAML_E_TOOLARGE;
-  if (D > scaml_fit_max_d(N)) return SCAML_E_TOOLARGE;
-  if (T == 0) return SCAML_OK;
-  scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, T, N, D, flags};
-  hipStream_t s = (hipStream_t)stream;
-  int rc;
-  if (N <= 32) rc = scaml::launch_fit<2, 1>(p, kind, s);
-  else if (N <= 64) rc = scaml::launch_fit<4, 1>(p, kind, s);
-  else if (N <= 128) rc = scaml::launch_fit<8, 3>(p, kind, s);
-  else rc = scaml::launch_fit<16, 7>(p, kind, s);
-  if (rc == SCAML_E_LAUNCH) {
-    hipError_t e = hipGetLastError();
-    snprintf(g_last_error, sizeof(g_last_error), "%s", hipGetErrorString(e));
-  }
-  return rc;
-}
-
-}  // extern "C"
+// Explicit instantiations: one kernel per padded size class (NB 16-blocks, WU update waves) and
+// kernel kind (see VGPR_CAPS in __graft_entry__.py for the register budgets).
+#define SCAML_INSTANTIATE(NB, WU)                                                   \
+  template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 0>(scaml::FitParams); \
+  template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 1>(scaml::FitParams);
+SCAML_INSTANTIATE(2, 1)
+SCAML_INSTANTIATE(4, 1)
+SCAML_INSTANTIATE(8, 3)
+SCAML_INSTANTIATE(16, 7)

@@ -49,48 +49,41 @@ __device__ __forceinline__ double sqrt_from_rinv(double d, double rinv) {
   return __builtin_fma(r, 0.5 * rinv, g);
 }
 
-// exp(x) for x <= 0 (kernel values).  n = rint(x log2 e), r = x - n ln2 (two-part), degree-13
-// Taylor on |r| <= 0.3466 (truncation 2e-17 rel.), scaled by 2^n with v_ldexp_f64.  Max
-// observed error vs libm < 2 ulp; returns 0 below -745.
-__device__ __forceinline__ double exp_neg(double x) {
+// exp(x) for x <= 0 (kernel values), table driven to keep the fp64 constant count (= registers)
+// low: n = rint(x * 64/ln2), x = n ln2/64 + r with |r| <= ln2/128, exp(x) = 2^(n>>6) * T[n&63] *
+// (1 + r + r^2/2 + r^3/6 + r^4/24 + r^5/120); the truncated term r^6/720 < 4e-17.  T[j] = 2^(j/64)
+// lives in LDS (exp2_table_init).  Max error vs libm ~1 ulp; returns 0 below -745.
+__device__ __forceinline__ void exp2_table_init(double* tab, int tid) {
+  if (tid < 64) tab[tid] = exp2((double)tid * (1.0 / 64.0));
+}
+
+__device__ __forceinline__ double exp_neg(double x, const double* tab) {
   x = x < -746.0 ? -746.0 : x;
-  double n = __builtin_rint(x * 1.4426950408889634074);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;            // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);   // 1/12!
-  p = __builtin_fma(p, r, 2.505210838544172e-08);  // 1/11!
-  p = __builtin_fma(p, r, 2.755731922398589e-07);  // 1/10!
-  p = __builtin_fma(p, r, 2.7557319223985893e-06); // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873e-05);   // 1/8!
-  p = __builtin_fma(p, r, 1.984126984126984e-04);  // 1/7!
-  p = __builtin_fma(p, r, 1.388888888888889e-03);  // 1/6!
-  p = __builtin_fma(p, r, 8.333333333333333e-03);  // 1/5!
-  p = __builtin_fma(p, r, 4.1666666666666664e-02); // 1/4!
-  p = __builtin_fma(p, r, 1.6666666666666666e-01); // 1/3!
+  const double nf = __builtin_rint(x * 92.332482616893656877);     // 64 / ln 2
+  double r = __builtin_fma(nf, -0x1.62e42fee00000p-7, x);   // ln2/64, high part (21 trailing zero bits: nf * hi is exact)
+  r = __builtin_fma(nf, -0x1.a39ef35793c76p-39, r);          // ln2/64, low part
+  const int n = (int)nf;
+  const double t = tab[n & 63];
+  double p = __builtin_fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
   p = __builtin_fma(p, r, 0.5);
-  p = __builtin_fma(p, r, 1.0);
-  p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)n);
+  p = __builtin_fma(p * r, r, r);     // r + r^2 (1/2 + ...)
+  return __builtin_ldexp(__builtin_fma(t, p, t), n >> 6);
 }
 
 // k(d2) for squared scaled distance d2 >= 0 (without the outputscale).
 template <int KIND>
-__device__ __forceinline__ double kernel_from_sqdist(double d2) {
+__device__ __forceinline__ double kernel_from_sqdist(double d2, const double* exp_tab) {
   if (KIND == 0) {  // RBF: exp(-d2/2)
-    return exp_neg(-0.5 * d2);
+    return exp_neg(-0.5 * d2, exp_tab);
   } else {          // Matern-5/2: gpytorch clamps d2 at 1e-30 before the sqrt
     double dd = d2 < 1e-30 ? 1e-30 : d2;
-    double r;
-    if (dd <= 1e30) {
-      double ri = rsqrt_seeded(dd);
-      r = sqrt_from_rinv(dd, ri);
-    } else {
-      r = sqrt(dd);
-    }
+    dd = dd > 1e30 ? 1e30 : dd;  // k == 0 out there; keeps the f32-seeded rsqrt in range
+    const double ri = rsqrt_seeded(dd);
+    const double r = sqrt_from_rinv(dd, ri);
     const double s5 = 2.2360679774997896964;
     double poly = __builtin_fma(__builtin_fma(r, 5.0 / 3.0, s5), r, 1.0);
-    return poly * exp_neg(-s5 * r);
+    return poly * exp_neg(-s5 * r, exp_tab);
   }
 }
 

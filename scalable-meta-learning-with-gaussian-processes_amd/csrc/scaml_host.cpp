@@ -1,0 +1,133 @@
+// scaml_host.cpp — host side of libscaml_hip.so: the C ABI of include/scaml_gp.h on top of the
+// gfx950 code object built from csrc/*.hip.
+//
+// The device code is compiled separately (see __graft_entry__.build): hipcc emits device LLVM IR,
+// csrc/patch_ir.py adds the function attributes clang cannot express ("amdgpu-agpr-alloc"="0":
+// the compiler may not touch the AGPR half of the register file, which the kernels manage by
+// hand; per-kernel "amdgpu-num-vgpr"), clang lowers it to a code object that is embedded below
+// and loaded through the HIP module API on first use.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+
+#include "../../include/scaml_gp.h"
+#include "gp_fit_params.h"
+
+extern "C" const unsigned char scaml_hsaco_blob[];   // generated: lib/hsaco_blob.c
+extern "C" const unsigned long scaml_hsaco_blob_len;
+
+namespace {
+
+thread_local char g_last_error[256] = "";
+
+void set_error(const char* what, hipError_t e) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr int PP = 17;  // LDS panel pitch, must match csrc/gp_fit_fused.hip
+
+struct FitVariant {
+  int nb, wu;
+  hipFunction_t fn[2];  // [kind]
+};
+
+struct Module {
+  std::mutex mu;
+  bool loaded = false;
+  hipModule_t mod = nullptr;
+  FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 1, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
+  hipError_t load() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (loaded) return hipSuccess;
+    hipError_t e = hipModuleLoadData(&mod, scaml_hsaco_blob);
+    if (e != hipSuccess) return e;
+    for (auto& v : fit) {
+      for (int kind = 0; kind < 2; ++kind) {
+        char name[128];
+        snprintf(name, sizeof(name), "_ZN5scaml19gp_fit_fused_kernelILi%dELi%dELi%dEEEvNS_9FitParamsE", v.nb, v.wu, kind);
+        e = hipModuleGetFunction(&v.fn[kind], mod, name);
+        if (e != hipSuccess) return e;
+        // the kernels use up to the full 160 KiB of LDS
+        e = hipFuncSetAttribute((const void*)v.fn[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+      }
+    }
+    loaded = true;
+    return hipSuccess;
+  }
+};
+
+Module& module() {
+  static Module m;
+  return m;
+}
+
+size_t fit_lds_bytes(int nb, int D) {
+  const int np = nb * 16;
+  size_t regionA = (size_t)2 * np * PP + (size_t)nb * 16 * PP;
+  if ((size_t)D * np > regionA) regionA = (size_t)D * np;
+  return (regionA + 4 * np + 128 + D + (D & 1) + 2) * sizeof(double);
+}
+
+}  // namespace
+
+extern "C" {
+
+int scaml_version(void) { return 300; }  // 0.3.0
+const char* scaml_last_error(void) { return g_last_error; }
+int scaml_fit_max_n(void) { return 256; }
+
+int scaml_fit_max_d(int N) {
+  // largest D whose staged point stack fits the 160 KiB LDS next to the vectors
+  int np = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
+  int budget = 160 * 1024 / 8 - 4 * np - 128 - 4;
+  int d = budget / (np + 1);
+  return d > 1024 ? 1024 : d;
+}
+
+int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta,
+                           const int32_t* n_points, const double* jitter_in,
+                           int T, int N, int D, int kind,
+                           double* L, double* alpha, double* quad, double* logdet, double* mll,
+                           int32_t* info, double* jitter_used, unsigned flags, void* stream) {
+  if (T < 0 || N < 1 || D < 1) return SCAML_E_BADARG;
+  if (!X || !y || !theta || !info) return SCAML_E_BADARG;
+  if ((flags & SCAML_FIT_STORE_L) && !L) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (N > scaml_fit_max_n()) return SCAML_E_TOOLARGE;
+  if (D > scaml_fit_max_d(N)) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) {
+    set_error("loading the gfx950 code object", e);
+    return SCAML_E_LAUNCH;
+  }
+  const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
+  const size_t lds = fit_lds_bytes(v.nb, D);
+  if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
+  scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, T, N, D, flags};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(v.fn[kind], (unsigned)T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
+                            (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) {
+    set_error("hipModuleLaunchKernel(gp_fit_fused)", e);
+    return SCAML_E_LAUNCH;
+  }
+  return SCAML_OK;
+}
+
+// Diagnostic builds only (SCAML_STAMPS): point the device-side stamp buffer at caller memory.
+int scaml_debug_set_stamp_buffer(long long* buf) {
+  Module& m = module();
+  if (m.load() != hipSuccess) return SCAML_E_LAUNCH;
+  hipDeviceptr_t sym = nullptr;
+  size_t bytes = 0;
+  if (hipModuleGetGlobal(&sym, &bytes, m.mod, "g_stamp_buf") != hipSuccess) return SCAML_E_BADARG;
+  return hipMemcpyHtoD(sym, &buf, sizeof(buf)) == hipSuccess ? 0 : SCAML_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -24,8 +24,8 @@ for _ in range(3):
     assert rc == 0
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
-names = ["load X,y", "K-build", "P1 spill+bar", "P2 potf2(w0)", "P2 barrier wait", "P3 trsm rows", "P3 barrier wait", "P4 mfma update", "tail barrier", "scalars+backsub"]
-med = np.median(s, 0); tot = med[:10].sum()
+names = ["load X,y", "K-build", "prologue (spill0+potf2)", "T: trsm+final stores", "Z barrier wait", "U1: col k+1 upd+spill", "X barrier wait", "U2: bulk update", "Y barrier wait (potf2)", "loop exit barrier", "scalars+backsub"]
+med = np.median(s, 0); tot = med[:11].sum()
 for i, nm in enumerate(names):
-    print(f"{nm:18s} {med[i]:10.0f} ticks  {100*med[i]/tot:5.1f}%")
-print(f"total {tot:.0f} ticks (s_memtime: 100 MHz constant clock => {tot/100:.1f} us)" )
+    print(f"{nm:26s} {med[i]:10.0f} cyc  {100*med[i]/tot:5.1f}%")
+print(f"total {tot:.0f} shader cycles (update wave 0 timeline) ~ {tot/2.4e3:.1f} us at 2.4 GHz")
