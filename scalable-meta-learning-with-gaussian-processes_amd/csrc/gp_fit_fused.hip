@@ -32,12 +32,13 @@
 #include "gp_fit_params.h"
 
 #ifdef SCAML_STAMPS
-// Diagnostic build only (tools/build_stamps.sh): thread 0 of every workgroup accumulates
-// s_memtime deltas per phase into a caller-provided buffer [T][16].  Never in libscaml_hip.so.
+// Diagnostic build only (python __graft_entry__.py --stamps): update wave 0 and the panel wave of
+// every workgroup accumulate s_memtime deltas per phase into a caller-provided buffer [T][2][16].
+// Never compiled into libscaml_hip.so.
 __device__ long long* g_stamp_buf = nullptr;
 #define STAMP_DECL long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[16] = {0}
 #define STAMP(i) do { long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; } while (0)
-#define STAMP_FLUSH(task) do { if (g_stamp_buf && threadIdx.x == 0) for (int i_ = 0; i_ < 16; ++i_) g_stamp_buf[(task) * 16 + i_] = st_acc[i_]; } while (0)
+#define STAMP_FLUSH(task) do { if (g_stamp_buf && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64)) for (int i_ = 0; i_ < 16; ++i_) g_stamp_buf[((task) * 2 + (threadIdx.x != 0)) * 16 + i_] = st_acc[i_]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -81,35 +82,50 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
   const int off_trash = (int)(trash - panel) + lane;
   const int off_prow = (16 * k + lc) * PP;    // + c   -> L[lc][c]
   const int off_w = (int)(Wk - panel) + lc;   // + c*PP -> W[c][lc]
+  // Pivot chain per step: rsqrt(dpiv) -> ri^2 -> next dpiv.  Everything else hangs off it: the raw
+  // row values are masked and read across lanes as soon as the previous MFMA lands (before ri is
+  // known), the range check only feeds `bad`, the two MFMAs and the LDS stores trail behind.
   int bad = 0;
   double dpiv = readlane_f64(a[0], 0);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int g = c & 3, rg = c >> 2;
-    if (!(dpiv >= 1e-30 && dpiv <= 1e30)) {  // non-positive, NaN or outside the seeded rsqrt range
-      if (!bad) bad = 16 * k + c + 1;
-      dpiv = 1.0;
-    }
-    const double ri = rsqrt_seeded(dpiv);
     const bool mine = lq == g;
     const bool low = (unsigned)(lane - (16 * g + c)) < (unsigned)(16 - c);  // mine && lc >= c
-    const double lcol = low ? a[rg] * ri : 0.0;   // L[lc][c]
-    const double wrow = mine ? R[rg] * ri : 0.0;  // W[c][lc]
+    const double am = low ? a[rg] : 0.0;    // raw column c (row c of the symmetric block), masked
+    const double Rm = mine ? R[rg] : 0.0;
+#ifndef PROBE_NO_OOB
+    // non-positive, NaN (or too small for the f32-seeded rsqrt): remember the first failing step;
+    // the garbage it produces afterwards is never used
+    if (!(dpiv >= 1e-30) && bad == 0) bad = 16 * k + c + 1;
+#endif
+    const double ri = rsqrt_seeded(dpiv);
     if (c < 15) {
       const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
-      const double lnext = readlane_f64(lcol, 16 * g + c + 1);
-      const double anext = readlane_f64(a[rg1], 16 * g1 + c + 1);
-      dpiv = __builtin_fma(-lnext, lnext, anext);
-      a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
-      R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
+      const double acn = readlane_f64(a[rg], 16 * g + c + 1);      // a[c+1][c] before scaling
+      const double anext = readlane_f64(a[rg1], 16 * g1 + c + 1);  // a[c+1][c+1]
+      dpiv = __builtin_fma(-(acn * acn), ri * ri, anext);
     }
+    const double lcol = am * ri;   // L[lc][c]
+    const double wrow = Rm * ri;   // W[c][lc]
+    if (c < 15) {
+      a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
+#ifndef PROBE_NO_INV
+      R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
+#endif
+    }
+#ifndef PROBE_NO_STORE
     panel[mine ? off_prow + c : off_trash] = lcol;
     panel[mine ? off_w + c * PP : off_trash] = wrow;
+#endif
   }
-  // v_k = W y_k (row lc of W per lane; lane groups replicate)
+  // v_k = W y_k: lane (lc, lq) takes the four terms c = 4 lq .. 4 lq + 3 of row lc, then the lane
+  // groups are summed
   double v = 0.0;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) v = __builtin_fma(Wk[lc * PP + c], ytil[16 * k + c], v);
+  for (int c = 0; c < 4; ++c) v = __builtin_fma(Wk[lc * PP + 4 * lq + c], ytil[16 * k + 4 * lq + c], v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   if (lq == 0) vv[16 * k + lc] = v;
   return bad;
 }
@@ -216,7 +232,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* dl = ww + NP;           // [NP] diag(L)
   double* trash = dl + NP;        // [64] per-lane dump slot of the panel wave
   double* exptab = trash + 64;    // [64] 2^(j/64) for exp_neg
-  double* invl = exptab + 64;     // [D]  1 / lengthscale
+  int* rowlist = (int*)(exptab + 64);  // [WU][NB][8]: count, then up to 7 packed (slot << 8 | column) per block row
+  double* invl = exptab + 64 + WU * NB * 4;  // [D]  1 / lengthscale
   int* flagp = (int*)(invl + p.D + (p.D & 1));  // [2] fail index
 
   const int task = blockIdx.x;
@@ -253,6 +270,21 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     if (tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
     exp2_table_init(exptab, tid);
+    if (!is_panel && lane == 0) {
+      // which off-diagonal tiles of each block row this wave holds (for the back-substitution)
+      int* rl = rowlist + wave * NB * 8;
+      for (int i = 0; i < NB; ++i) rl[8 * i] = 0;
+      int j = 0, r = wave;
+      for (int s = 0; s < SLOTS; ++s) {
+        while (j < NB && r >= NB - j) { r -= NB - j; ++j; }
+        if (j >= NB) break;
+        if (r > 0) {
+          const int i = j + r, c = rl[8 * i];
+          if (c < 7) { rl[8 * i + 1 + c] = (s << 8) | j; rl[8 * i] = c + 1; }
+        }
+        r += WU;
+      }
+    }
     __syncthreads();
     // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
     for (int r = tid; r < NP; r += NTHREADS) {
@@ -428,7 +460,11 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         __syncthreads();  // X: column k+1 (raw) and the updated right-hand side visible to the panel wave
         STAMP(6);
         if (is_panel) {
+          // the panel wave is the youngest wave on its SIMD and would lose every issue slot to the
+          // update wave streaming MFMAs next to it: raise its priority for the pivot chain
+          __builtin_amdgcn_s_setprio(3);
           int bad = potf2_inv_block(nbuf, WAll + (k + 1) * 16 * PP, vv, trash, ytil, k + 1, lane);
+          __builtin_amdgcn_s_setprio(0);
           if (bad && lane == 0) flagp[0] = bad;
         } else {
           // U2: the bulk of the trailing update, overlapped with the panel wave: every slot from
@@ -483,41 +519,49 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       }
     }
     if (p.alpha) {
+      // alpha = L^-T v by blocks from the bottom.  Per block k every wave forms alpha_k = W_k^T w_k
+      // itself (a 16x16 mat-vec out of LDS: four terms per lane group, then two cross-group adds),
+      // the update waves then fold alpha_k into w_j for the tiles (k, j) they hold in registers; one
+      // barrier per block.
       for (int r = tid; r < NP; r += NTHREADS) ww[r] = vv[r];
       __syncthreads();
+      STAMP(11);
       for (int k = NB - 1; k >= 0; --k) {
-        if (is_panel) {
-          // alpha_k = L_kk^-T w_k = W^T w_k: lane m accumulates sum_c W[c][m] w_c
-          const double* Wk = WAll + k * 16 * PP;
-          double a = 0.0;
+        const double* Wk = WAll + k * 16 * PP;
+        double ak = 0.0;
 #pragma unroll
-          for (int c = 0; c < 16; ++c) a = __builtin_fma(Wk[c * PP + lc], ww[16 * k + c], a);
-          if (lq == 0) ww[16 * k + lc] = a;
-        }
-        __syncthreads();
-        if (!is_panel) {
-          // w_j -= L_kj^T alpha_k for the tiles (k, j), j < k, this wave holds
-          const double* wk = ww + 16 * k + lq;
-          for (int j = 0; j < k; ++j) {
-            const int t = off(j) + (k - j);
-            if (t % WU == wave) {
-              const int s = t / WU;
-              double e0, e1, e2, e3;
+        for (int c = 0; c < 4; ++c) ak = __builtin_fma(Wk[(4 * lq + c) * PP + lc], ww[16 * k + 4 * lq + c], ak);
+        ak += __shfl_xor(ak, 16);
+        ak += __shfl_xor(ak, 32);   // every lane (lc, *) now holds alpha_k[lc]
+        STAMP(12);
+        if (is_panel) {
+          if (lq == 0) dl[16 * k + lc] = ak;   // dl is free by now: alpha is collected there
+        } else {
+          // alpha_k[lq + 4 g] for the four rows of this lane's tile elements
+          const double a0 = __shfl(ak, lq), a1 = __shfl(ak, lq + 4), a2 = __shfl(ak, lq + 8), a3 = __shfl(ak, lq + 12);
+          // tiles (k, j), j < k, held by this wave
+          const int* rl = rowlist + (wave * NB + k) * 8;
+          const int cnt = rl[0];
+          for (int i = 0; i < cnt; ++i) {
+            const int sj = rl[1 + i], s = sj >> 8, j = sj & 0xff;
+            double e0, e1, e2, e3;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
-              SCAML_DISPATCH(s)
+            SCAML_DISPATCH(s)
 #undef SCAML_BODY
-              double part = e0 * wk[0];
-              part = __builtin_fma(e1, wk[4], part);
-              part = __builtin_fma(e2, wk[8], part);
-              part = __builtin_fma(e3, wk[12], part);
-              part += __shfl_xor(part, 16);
-              part += __shfl_xor(part, 32);
-              if (lq == 0) ww[16 * j + lc] -= part;
-            }
+            double part = e0 * a0;
+            part = __builtin_fma(e1, a1, part);
+            part = __builtin_fma(e2, a2, part);
+            part = __builtin_fma(e3, a3, part);
+            // four lane groups add into the same w_j entry: LDS fp64 atomic, no return value
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ww + 16 * j + lc), -part);
           }
         }
+        STAMP(13);
         __syncthreads();
+        STAMP(14);
       }
+      for (int r = tid; r < NP; r += NTHREADS) ww[r] = dl[r];
+      __syncthreads();
       for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = ww[r];
     }
   }
@@ -536,6 +580,7 @@ __global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p
   // jitter escalation of linear_operator's psd_safe_cholesky, per task, without leaving the GPU
   double jitter = 0.0;
   int fail = gp_fit_attempt<NB, WU, KIND>(p, 0.0);
+#ifndef SCAML_STAMPS  // (the diagnostic build times the first attempt only)
   if (fail && !(p.flags & SCAML_FIT_NO_RETRY)) {
     const FitParams pc = p;  // only this cold copy has its address taken; `p` stays in the kernarg segment
     for (int attempt = 1; attempt < 4 && fail; ++attempt) {
@@ -543,6 +588,7 @@ __global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p
       fail = gp_fit_retry<NB, WU, KIND>(pc, jitter);
     }
   }
+#endif
   if (threadIdx.x == 0) {
     const int task = blockIdx.x;
     if (fail) {

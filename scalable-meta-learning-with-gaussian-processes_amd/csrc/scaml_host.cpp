@@ -64,11 +64,11 @@ Module& module() {
   return m;
 }
 
-size_t fit_lds_bytes(int nb, int D) {
+size_t fit_lds_bytes(int nb, int wu, int D) {
   const int np = nb * 16;
   size_t regionA = (size_t)2 * np * PP + (size_t)nb * 16 * PP;
   if ((size_t)D * np > regionA) regionA = (size_t)D * np;
-  return (regionA + 4 * np + 128 + D + (D & 1) + 2) * sizeof(double);
+  return (regionA + 4 * np + 128 + (size_t)wu * nb * 4 + D + (D & 1) + 2) * sizeof(double);
 }
 
 }  // namespace
@@ -82,7 +82,7 @@ int scaml_fit_max_n(void) { return 256; }
 int scaml_fit_max_d(int N) {
   // largest D whose staged point stack fits the 160 KiB LDS next to the vectors
   int np = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
-  int budget = 160 * 1024 / 8 - 4 * np - 128 - 4;
+  int budget = 160 * 1024 / 8 - 4 * np - 128 - 7 * 16 * 4 - 4;
   int d = budget / (np + 1);
   return d > 1024 ? 1024 : d;
 }
@@ -106,7 +106,7 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
     return SCAML_E_LAUNCH;
   }
   const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
-  const size_t lds = fit_lds_bytes(v.nb, D);
+  const size_t lds = fit_lds_bytes(v.nb, v.wu, D);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
   scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, T, N, D, flags};
   size_t psize = sizeof(p);
