@@ -60,9 +60,11 @@ def make_inputs(rank: int, device):
     return (X, y, th), (X.to(device), y.to(device), th.to(device))
 
 
-def cpu_baseline(host_inputs, budget_s: float = 12.0):
-    """Time the oracle's per-task loop (the reference's shape of work, scamlgp/model.py:176-188)
-    on the host cores over a bounded sample of the bench workload."""
+def cpu_baseline(host_inputs, budget_s: float = 8.0):
+    """Time the oracle on the host cores over a bounded sample of the bench workload, two ways:
+    the reference's shape of work — a per-task Python loop (scamlgp/model.py:176-188), one dense
+    Cholesky per task — and the same arithmetic as one batched torch.linalg call.  The faster of
+    the two is reported as the baseline value; both are named in `sample`."""
     import torch
     from oracle import gp_oracle as O
 
@@ -79,8 +81,21 @@ def cpu_baseline(host_inputs, budget_s: float = 12.0):
         el = time.perf_counter() - t0
         if el > budget_s or done >= 4 * T_PER_GPU:
             break
-    return dict(value=done / el, unit="task-posteriors/s", cores=cores, kind="port",
-                sample=f"{done} tasks of the bench workload (per-task torch-fp64 loop, {el:.1f} s)")
+    loop_rate = done / el
+    O.gp_fit_stack_batched(X[:8], y[:8], th[:8], O.KIND_MATERN52)  # warm-up
+    chunk, done_b = 64, 0
+    t0 = time.perf_counter()
+    while True:
+        lo = done_b % T_PER_GPU
+        O.gp_fit_stack_batched(X[lo:lo + chunk], y[lo:lo + chunk], th[lo:lo + chunk], O.KIND_MATERN52)
+        done_b += chunk
+        el_b = time.perf_counter() - t0
+        if el_b > budget_s or done_b >= 8 * T_PER_GPU:
+            break
+    batched_rate = done_b / el_b
+    return dict(value=max(loop_rate, batched_rate), unit="task-posteriors/s", cores=cores, kind="port",
+                sample=(f"torch-fp64 oracle on the bench workload: per-task loop {done} tasks in {el:.1f} s = {loop_rate:.1f}/s; "
+                        f"batched torch.linalg (64-task chunks) {done_b} tasks in {el_b:.1f} s = {batched_rate:.1f}/s"))
 
 
 def main():
@@ -178,7 +193,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
-                "kernel": "gp_fit_fused_kernel<16,8,matern52>",
+                "kernel": "gp_fit_fused_kernel<16,7,matern52>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": algorithmic_bytes_per_task(N_POINTS, DIM) * T_PER_GPU,
