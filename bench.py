@@ -42,6 +42,17 @@ def algorithmic_bytes_per_task(N: int, D: int) -> float:
     return 8.0 * (N * D + N + D + 2) + 8.0 * (N * N + N + 3) + 4 + 8
 
 
+def recorded_pmc_traffic():
+    """HBM bytes per launch of the fused-fit kernel from the rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, one pass each, same command line as this bench) — recorded in profiles/, because
+    counters cannot be collected from inside the timed process.  None if no record exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(path))["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_inputs(rank: int, device):
     import numpy as np
     import torch
@@ -192,7 +203,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": recorded_pmc_traffic(),
                 "kernel": "gp_fit_fused_kernel<16,7,matern52>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops,
