@@ -66,14 +66,51 @@ int scaml_fit_max_d(int N);         /* largest D for that N (LDS budget)        
  * added to its diagonal (only that task); jitter_used[t] reports the value that succeeded,
  * info[t] > 0 that all attempts failed.  `jitter_in` (T) may be NULL; if given it is added to
  * every attempt (caller-controlled extra jitter).
- * Outputs L, alpha, quad, logdet, mll, jitter_used may individually be NULL (not written);
- * info must not be NULL.
+ * Linv_diag (T, ceil(N/16), 16, 16), optional: the inverses of the 16x16 diagonal blocks of L
+ * (identity-padded past n_t); scaml_posterior_batched_f64 needs them.
+ * Outputs L, alpha, quad, logdet, mll, jitter_used, Linv_diag may individually be NULL (not
+ * written); info must not be NULL.
  */
 int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta,
                            const int32_t* n_points, const double* jitter_in,
                            int T, int N, int D, int kind,
                            double* L, double* alpha, double* quad, double* logdet, double* mll,
-                           int32_t* info, double* jitter_used, unsigned flags, void* stream);
+                           int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream);
+
+/*
+ * (5) Batched source-GP posteriors at M query points shared by all tasks.
+ * Replaces the per-source loop `[gp.posterior(x) for gp in source_gps]` of
+ *   scamlgp/model.py:128 (inside _compute_target_prior) and :281 (ScaMLGP.__init__ caches)
+ * i.e. gpytorch's exact prediction mu~ = K_* alpha, Sigma~ = k(x,x) - V^T V with V = L^-1 K_*^T,
+ * followed by botorch's Standardize.untransform_posterior (mu = m + s mu~, Sigma = s^2 Sigma~;
+ * y_mean / y_std (T) may be NULL = 0 / 1).  No observation noise is added.
+ *   Xq (M, D); L, alpha, Linv_diag as produced by scaml_gp_fit_fused_f64 with the same X, theta.
+ *   mu (T, M), var (T, M) = diagonal of Sigma, V (T, N, M) = L^-1 K_*^T (un-scaled): each may be
+ *   NULL.  N <= scaml_posterior_max_n().
+ */
+int scaml_posterior_max_n(void);
+int scaml_posterior_batched_f64(const double* Xq, const double* X, const double* theta, const double* L,
+                                const double* Linv_diag, const double* alpha, const double* y_mean,
+                                const double* y_std, const int32_t* n_points, int T, int N, int M, int D, int kind,
+                                double* mu, double* var, double* V, void* stream);
+
+/*
+ * (5b) Covariance block of the same posteriors between the first Ma query points and all M:
+ *   cov[t][a][c] = y_std[t]^2 (os k(xq_a, xq_c) - sum_i V[t][i][a] V[t][i][c]),  cov (T, Ma, M).
+ * With the target's training points placed first in Xq this yields Sigma_nn and Sigma_nq of
+ * scamlgp/model.py:287-289 / :131 without recomputing the train block per query.
+ */
+int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double* V, const double* y_std,
+                            int T, int N, int M, int Ma, int D, int kind, double* cov, void* stream);
+
+/*
+ * (6) Weighted sum over the task axis: out[e] = sum_t c_t in[t][e], c_t = w_t (power 1) or w_t^2
+ * (power 2), tasks with active[t] == 0 skipped (active may be NULL).  in (T, len), out (len).
+ * Replaces scamlgp/model.py:129-135: mean = sum_i w_i mu_i (power 1), cov = sum_i w_i^2 Sigma_i
+ * (power 2, PsdSumLinearOperator) over the significant tasks of model.py:368-372.
+ */
+int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t* active, int T, long long len,
+                                int power, double* out, void* stream);
 
 #ifdef __cplusplus
 }

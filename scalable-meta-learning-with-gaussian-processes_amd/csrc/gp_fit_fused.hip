@@ -518,6 +518,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (p.mll) p.mll[task] = n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0;
       }
     }
+    if (p.Linv_diag) {
+      // W_k = L_kk^-1 for every diagonal block, (T, ceil(N/16), 16, 16): the batched posterior solves
+      // L^-1 K_*^T with them on the matrix cores instead of by substitution
+      const int nbn = (N + 15) / 16;
+      double* Wg = p.Linv_diag + (size_t)task * nbn * 256;
+      for (int e = tid; e < nbn * 256; e += NTHREADS) Wg[e] = WAll[(e >> 4) * PP + (e & 15)];
+    }
     if (p.alpha) {
       // alpha = L^-T v by blocks from the bottom.  Per block k every wave forms alpha_k = W_k^T w_k
       // itself (a 16x16 mat-vec out of LDS: four terms per lane group, then two cross-group adds),

@@ -17,6 +17,7 @@ struct FitParams {
   double* mll;
   int32_t* info;
   double* jitter_used;
+  double* Linv_diag;
   int T, N, D;
   unsigned flags;
 };

@@ -1,0 +1,196 @@
+// gp_posterior.hip — batched source-GP posteriors at shared query points, their cross-covariance
+// blocks, and the weighted sum over tasks that forms the ScaML-GP target prior (gfx950).
+//
+// Replaces, for all source tasks at once,
+//   scamlgp/model.py:128, 281   posteriors = [gp.posterior(x) for gp in source_gps]
+//       (botorch GPyTorchModel.posterior -> gpytorch ExactGP eval / DefaultPredictionStrategy:
+//        mu~ = K_* alpha,  Sigma~ = k(x,x) - V^T V with V = L^-1 K_*^T,  then
+//        Standardize.untransform_posterior: mu = m + s mu~, Sigma = s^2 Sigma~)
+//   scamlgp/model.py:129-135    mean = sum_i w_i mu_i,  cov = sum_i w_i^2 Sigma_i
+//
+// gp_posterior_kernel: one wave per (task, strip of 16 query points), waves fully independent.
+//   Row block kb of V = L^-1 K_*^T:  V_kb = W_kb (K_*^T_kb - sum_{j<kb} L_kb,j V_j), W_kb = L_kk^-1
+//   (from the fused fit).  The cross-kernel block is evaluated straight into an MFMA accumulator
+//   (C/D layout: col = lane & 15 = query point, row = (lane >> 4) + 4g = training point), every
+//   L_kb,j V_j product is 4 v_mfma_f64_16x16x4_f64 (A = L tile from HBM/L2, B = V_j from the wave's
+//   LDS strip); the accumulator registers are already in B-operand position for the final W_kb
+//   product (row 4m + (lane >> 4) of the tile is register m), so no data moves between the two.
+//   mean and variance are reduced on the fly; V can be kept for the covariance kernel.
+#include "scaml_common.hpp"
+#include "../../include/scaml_gp.h"
+#include "gp_posterior_params.h"
+
+namespace scaml {
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
+  extern __shared__ double lds[];
+  const int N = p.N, D = p.D, M = p.M;
+  const int NB = (N + 15) / 16, NP = NB * 16;
+  const int task = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  int n = p.n_points ? p.n_points[task] : N;
+  n = n < 0 ? 0 : (n > N ? N : n);
+  // LDS: exp table [64] | alpha [NP] | invl [D] (+pad) | xsT [D][NP] (optional) | per wave: xq [D][16], V strip [NP][16]
+  double* exptab = lds;
+  double* alpha_s = exptab + 64;
+  double* invl = alpha_s + NP;
+  double* xsT = invl + D + (D & 1);
+  double* wbase = xsT + (p.x_in_lds ? D * NP : 0);
+  double* xqs = wbase + wave * (16 * D + NP * 16);
+  double* Vs = xqs + 16 * D;
+
+  const double* Xg = p.X + (size_t)task * N * D;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * NB * 256;
+  const double os = th[D];
+  const double ym = p.y_mean ? p.y_mean[task] : 0.0;
+  const double ys = p.y_std ? p.y_std[task] : 1.0;
+
+  exp2_table_init(exptab, tid);
+  if (tid < D) invl[tid] = 1.0 / th[tid];
+  for (int r = tid; r < NP; r += blockDim.x) alpha_s[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
+  __syncthreads();
+  if (p.x_in_lds) {
+    for (int r = tid; r < NP; r += blockDim.x) {
+      const bool in = r < n;
+      for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+    }
+  }
+  const int strip = blockIdx.x * nwaves + wave;
+  const int c0 = strip * 16;
+  const int qc = c0 + lc;   // this lane's query point
+  if (lq == 0) {
+    for (int d = 0; d < D; ++d) xqs[d * 16 + lc] = qc < M ? p.Xq[(size_t)qc * D + d] * invl[d] : 0.0;
+  }
+  __syncthreads();
+  if (c0 >= M) return;   // (no barrier below: waves are independent from here)
+
+  double mean_part = 0.0, var_part = 0.0;
+  for (int kb = 0; kb < NB; ++kb) {
+    // cross-kernel block K(X[16kb + row], xq[c]) straight into the accumulator
+    d4_t acc;
+    {
+      double d2[4] = {0.0, 0.0, 0.0, 0.0};
+      const int row0 = 16 * kb + lq;
+#pragma unroll 2
+      for (int d = 0; d < D; ++d) {
+        const double xc = xqs[d * 16 + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + 4 * g;
+          const double xr = p.x_in_lds ? xsT[d * NP + row] : (row < n ? Xg[(size_t)row * D + d] * invl[d] : 0.0);
+          const double df = xr - xc;
+          d2[g] = __builtin_fma(df, df, d2[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = row0 + 4 * g;
+        double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+        kv = row < n ? kv : 0.0;
+        acc[g] = kv;
+        mean_part = __builtin_fma(kv, alpha_s[row], mean_part);
+      }
+    }
+    // acc -= L[kb, j] V_j for the row blocks already solved
+    const int arow = 16 * kb + lc;
+    const bool arow_ok = arow < n;
+    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
+    for (int j = 0; j < kb; ++j) {
+      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int col = 16 * j + 4 * m + lq;
+        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);  // blgp = 1: -A
+      }
+    }
+    // V_kb = W_kb acc: register m of acc is row 4m + lq of the tile = the B operand of k-step m
+    d4_t v = {0.0, 0.0, 0.0, 0.0};
+    const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      var_part = __builtin_fma(v[g], v[g], var_part);
+      Vs[(16 * kb + lq + 4 * g) * 16 + lc] = v[g];
+      const int row = 16 * kb + lq + 4 * g;
+      if (p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = v[g];
+    }
+  }
+  mean_part += __shfl_xor(mean_part, 16);
+  mean_part += __shfl_xor(mean_part, 32);
+  var_part += __shfl_xor(var_part, 16);
+  var_part += __shfl_xor(var_part, 32);
+  if (lq == 0 && qc < M) {
+    if (p.mu) p.mu[(size_t)task * M + qc] = __builtin_fma(ys, mean_part, ym);
+    if (p.var) p.var[(size_t)task * M + qc] = ys * ys * (os - var_part);
+  }
+}
+
+// cov[t][a][c] = s_t^2 (os k(xq_a, xq_c) - sum_i V[t][i][a] V[t][i][c]) for a < Ma, c < M:
+// one wave per 16x16 output tile, contraction over the N training points on the matrix cores.
+template <int KIND>
+__global__ __launch_bounds__(256) void gp_posterior_cov_kernel(PosteriorCovParams p) {
+  __shared__ double exptab[64];
+  const int N = p.N, D = p.D, M = p.M, Ma = p.Ma;
+  const int task = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  exp2_table_init(exptab, tid);
+  __syncthreads();
+  const int ta = blockIdx.y, tc = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (16 * tc >= M) return;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double os = th[D];
+  const double ys = p.y_std ? p.y_std[task] : 1.0;
+  const double* Vg = p.V + (size_t)task * N * M;
+  // -V_a^T V_c: A operand lane (i = lc -> point a, k = lq -> training row), B operand lane (k = lq, j = lc -> point c)
+  const int pa = 16 * ta + lc, pc = 16 * tc + lc;
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  for (int i0 = 0; i0 < N; i0 += 4) {
+    const int i = i0 + lq;
+    const double a = (i < N && pa < Ma) ? Vg[(size_t)i * M + pa] : 0.0;
+    const double b = (i < N && pc < M) ? Vg[(size_t)i * M + pc] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 1);
+  }
+  // + os k(xq_a, xq_c) for the elements this lane owns: rows (points a) lq + 4g, column (point c) lc
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int a = 16 * ta + lq + 4 * g;
+    if (a < Ma && pc < M) {
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double df = (p.Xq[(size_t)a * D + d] - p.Xq[(size_t)pc * D + d]) / th[d];
+        d2 = __builtin_fma(df, df, d2);
+      }
+      const double kv = os * kernel_from_sqdist<KIND>(d2, exptab);
+      p.cov[((size_t)task * Ma + a) * M + pc] = ys * ys * (kv + acc[g]);
+    }
+  }
+}
+
+}  // namespace scaml
+
+// out[e] = sum_t coef(t) * in[t][e], coef = w_t (power 1) or w_t^2 (power 2), skipping masked tasks
+extern "C" __global__ void scaml_weighted_task_sum_kernel(const double* __restrict__ in, const double* __restrict__ w,
+                                         const uint8_t* __restrict__ active, int T, long long len, int power,
+                                         double* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  double s = 0.0;
+  for (int t = 0; t < T; ++t) {
+    if (active && !active[t]) continue;
+    const double c = power == 2 ? w[t] * w[t] : w[t];
+    s = __builtin_fma(c, in[(size_t)t * len + e], s);
+  }
+  out[e] = s;
+}
+
+template __global__ void scaml::gp_posterior_kernel<0>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_kernel<1>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_cov_kernel<0>(scaml::PosteriorCovParams);
+template __global__ void scaml::gp_posterior_cov_kernel<1>(scaml::PosteriorCovParams);

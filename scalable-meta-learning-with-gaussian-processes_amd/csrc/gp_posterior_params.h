@@ -1,0 +1,33 @@
+// Kernel-argument blocks of the posterior kernels, shared by device source and host launcher.
+#pragma once
+#include <stdint.h>
+
+namespace scaml {
+
+struct PosteriorParams {
+  const double* Xq;         // (M, D) query points, shared by all tasks
+  const double* X;          // (T, N, D)
+  const double* theta;      // (T, D+2)
+  const double* L;          // (T, N, N)
+  const double* Linv_diag;  // (T, ceil(N/16), 16, 16)
+  const double* alpha;      // (T, N)
+  const double* y_mean;     // (T) or NULL
+  const double* y_std;      // (T) or NULL
+  const int32_t* n_points;  // (T) or NULL
+  double* mu;               // (T, M) or NULL
+  double* var;              // (T, M) or NULL
+  double* V;                // (T, N, M) or NULL
+  int T, N, M, D;
+  int x_in_lds;
+};
+
+struct PosteriorCovParams {
+  const double* Xq;     // (M, D)
+  const double* theta;  // (T, D+2)
+  const double* V;      // (T, N, M)
+  const double* y_std;  // (T) or NULL
+  double* cov;          // (T, Ma, M)
+  int T, N, M, Ma, D;
+};
+
+}  // namespace scaml

@@ -14,6 +14,7 @@
 
 #include "../../include/scaml_gp.h"
 #include "gp_fit_params.h"
+#include "gp_posterior_params.h"
 
 extern "C" const unsigned char scaml_hsaco_blob[];   // generated: lib/hsaco_blob.c
 extern "C" const unsigned long scaml_hsaco_blob_len;
@@ -38,6 +39,9 @@ struct Module {
   bool loaded = false;
   hipModule_t mod = nullptr;
   FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 1, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
+  hipFunction_t post[2] = {nullptr, nullptr};
+  hipFunction_t post_cov[2] = {nullptr, nullptr};
+  hipFunction_t wsum = nullptr;
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
     if (loaded) return hipSuccess;
@@ -54,6 +58,15 @@ struct Module {
         if (e != hipSuccess) return e;
       }
     }
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      snprintf(name, sizeof(name), "_ZN5scaml19gp_posterior_kernelILi%dEEEvNS_15PosteriorParamsE", kind);
+      if ((e = hipModuleGetFunction(&post[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)post[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+      snprintf(name, sizeof(name), "_ZN5scaml23gp_posterior_cov_kernelILi%dEEEvNS_18PosteriorCovParamsE", kind);
+      if ((e = hipModuleGetFunction(&post_cov[kind], mod, name)) != hipSuccess) return e;
+    }
+    if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
     loaded = true;
     return hipSuccess;
   }
@@ -91,7 +104,7 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
                            const int32_t* n_points, const double* jitter_in,
                            int T, int N, int D, int kind,
                            double* L, double* alpha, double* quad, double* logdet, double* mll,
-                           int32_t* info, double* jitter_used, unsigned flags, void* stream) {
+                           int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream) {
   if (T < 0 || N < 1 || D < 1) return SCAML_E_BADARG;
   if (!X || !y || !theta || !info) return SCAML_E_BADARG;
   if ((flags & SCAML_FIT_STORE_L) && !L) return SCAML_E_BADARG;
@@ -108,7 +121,7 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
   const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
   const size_t lds = fit_lds_bytes(v.nb, v.wu, D);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
-  scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, T, N, D, flags};
+  scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag, T, N, D, flags};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(v.fn[kind], (unsigned)T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
@@ -117,6 +130,78 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
     set_error("hipModuleLaunchKernel(gp_fit_fused)", e);
     return SCAML_E_LAUNCH;
   }
+  return SCAML_OK;
+}
+
+// ---- (5) batched source posteriors ------------------------------------------------------------
+static size_t posterior_lds_bytes(int N, int D, int waves, bool x_in_lds) {
+  const size_t np = (size_t)((N + 15) / 16) * 16;
+  return (64 + np + D + (D & 1) + (x_in_lds ? (size_t)D * np : 0) + (size_t)waves * (16 * D + np * 16)) * sizeof(double);
+}
+
+int scaml_posterior_max_n(void) { return 512; }
+
+int scaml_posterior_batched_f64(const double* Xq, const double* X, const double* theta, const double* L,
+                                const double* Linv_diag, const double* alpha, const double* y_mean,
+                                const double* y_std, const int32_t* n_points, int T, int N, int M, int D, int kind,
+                                double* mu, double* var, double* V, void* stream) {
+  if (T < 0 || N < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
+  if (!Xq || !X || !theta || !L || !Linv_diag || !alpha) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0 || M == 0) return SCAML_OK;
+  // waves per workgroup / X staging: the largest configuration whose LDS fits 160 KiB
+  int waves = 0;
+  bool xl = true;
+  for (int cand : {4, 2, 1}) {
+    if (posterior_lds_bytes(N, D, cand, true) <= 160 * 1024) { waves = cand; xl = true; break; }
+    if (posterior_lds_bytes(N, D, cand, false) <= 160 * 1024) { waves = cand; xl = false; break; }
+  }
+  if (!waves) return SCAML_E_TOOLARGE;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  scaml::PosteriorParams p{Xq, X, theta, L, Linv_diag, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  const int strips = (M + 15) / 16;
+  e = hipModuleLaunchKernel(m.post[kind], (unsigned)((strips + waves - 1) / waves), (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
+                            (unsigned)posterior_lds_bytes(N, D, waves, xl), (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double* V, const double* y_std,
+                            int T, int N, int M, int Ma, int D, int kind, double* cov, void* stream) {
+  if (T < 0 || N < 1 || M < 0 || Ma < 0 || Ma > M || D < 1) return SCAML_E_BADARG;
+  if (!Xq || !theta || !V || !cov) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (T == 0 || M == 0 || Ma == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  scaml::PosteriorCovParams p{Xq, theta, V, y_std, cov, T, N, M, Ma, D};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  const int tiles_c = (M + 15) / 16, tiles_a = (Ma + 15) / 16;
+  e = hipModuleLaunchKernel(m.post_cov[kind], (unsigned)((tiles_c + 3) / 4), (unsigned)tiles_a, (unsigned)T, 256, 1, 1, 0,
+                            (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_cov)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+// ---- (6) weighted sum over tasks ---------------------------------------------------------------
+int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t* active, int T, long long len,
+                                int power, double* out, void* stream) {
+  if (T < 0 || len < 0 || (power != 1 && power != 2)) return SCAML_E_BADARG;
+  if (!in || !w || !out) return SCAML_E_BADARG;
+  if (len == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  void* args[] = {(void*)&in, (void*)&w, (void*)&active, (void*)&T, (void*)&len, (void*)&power, (void*)&out};
+  e = hipModuleLaunchKernel(m.wsum, (unsigned)((len + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(weighted_task_sum)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
 

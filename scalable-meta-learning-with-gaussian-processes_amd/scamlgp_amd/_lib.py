@@ -58,8 +58,20 @@ def _load() -> ctypes.CDLL:
         _dp, _dp, _dp, _dp, _dp,  # X, y, theta, n_points, jitter_in
         c_int, c_int, c_int, c_int,  # T, N, D, kind
         _dp, _dp, _dp, _dp, _dp,  # L, alpha, quad, logdet, mll
-        _dp, _dp, c_uint, c_void_p,  # info, jitter_used, flags, stream
+        _dp, _dp, _dp, c_uint, c_void_p,  # info, jitter_used, Linv_diag, flags, stream
     ]
+    lib.scaml_posterior_max_n.restype = c_int
+    lib.scaml_posterior_max_n.argtypes = []
+    lib.scaml_posterior_batched_f64.restype = c_int
+    lib.scaml_posterior_batched_f64.argtypes = [
+        _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,  # Xq, X, theta, L, Linv_diag, alpha, y_mean, y_std, n_points
+        c_int, c_int, c_int, c_int, c_int,  # T, N, M, D, kind
+        _dp, _dp, _dp, c_void_p,  # mu, var, V, stream
+    ]
+    lib.scaml_posterior_cov_f64.restype = c_int
+    lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]
+    lib.scaml_weighted_task_sum_f64.restype = c_int
+    lib.scaml_weighted_task_sum_f64.argtypes = [_dp, _dp, _dp, c_int, ctypes.c_longlong, c_int, _dp, c_void_p]
     return lib
 
 
@@ -72,6 +84,10 @@ EXPORTED_SYMBOLS = (
     "scaml_fit_max_n",
     "scaml_fit_max_d",
     "scaml_gp_fit_fused_f64",
+    "scaml_posterior_max_n",
+    "scaml_posterior_batched_f64",
+    "scaml_posterior_cov_f64",
+    "scaml_weighted_task_sum_f64",
 )
 
 

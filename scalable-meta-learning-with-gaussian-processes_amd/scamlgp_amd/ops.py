@@ -49,12 +49,14 @@ def gp_fit_fused(
     zero_upper: bool = True,
     retry: bool = True,
     want_alpha: bool = True,
+    want_linv: bool = False,
     out: Optional[Dict[str, torch.Tensor]] = None,
 ) -> Dict[str, torch.Tensor]:
     """K + noise, jittered Cholesky, alpha, quad, logdet, MLL for a stack of tasks.
 
     X (T, N, D), y (T, N), theta (T, D+2) = [lengthscales, outputscale, noise] (constrained).
-    Returns dict(L, alpha, quad, logdet, mll, info, jitter); ``L`` is None when store_L=False.
+    Returns dict(L, alpha, quad, logdet, mll, info, jitter, Linv_diag); ``L`` is None when
+    store_L=False, ``Linv_diag`` (T, ceil(N/16), 16, 16) only with want_linv=True.
     One launch of ``scaml_gp_fit_fused_f64`` (include/scaml_gp.h).  ``out`` may be the dict a
     previous call returned for the same shapes/flags: its tensors are reused (no allocation).
     """
@@ -72,6 +74,7 @@ def gp_fit_fused(
     with torch.cuda.device(dev):
         if out is not None:
             L, alpha, quad, logdet, mll, info, jit_used = (out[k] for k in ("L", "alpha", "quad", "logdet", "mll", "info", "jitter"))
+            linv = out.get("Linv_diag")
             if (L is None) == store_L or (alpha is None) == want_alpha or quad.shape != (T,) or (store_L and L.shape != (T, N, N)):
                 raise ValueError("out= does not match this call's shapes/flags")
         else:
@@ -82,6 +85,7 @@ def gp_fit_fused(
             mll = torch.empty((T,), dtype=torch.float64, device=dev)
             info = torch.empty((T,), dtype=torch.int32, device=dev)
             jit_used = torch.empty((T,), dtype=torch.float64, device=dev)
+            linv = torch.empty((T, (N + 15) // 16, 16, 16), dtype=torch.float64, device=dev) if want_linv else None
         if n_points is not None and want_alpha:
             alpha.zero_()
         flags = 0
@@ -97,10 +101,88 @@ def gp_fit_fused(
             _ptr(X), _ptr(y), _ptr(theta), _ptr(n_points), _ptr(jitter),
             T, N, D, int(kind),
             _ptr(L), _ptr(alpha), _ptr(quad), _ptr(logdet), _ptr(mll),
-            _ptr(info), _ptr(jit_used), flags, _stream_handle(),
+            _ptr(info), _ptr(jit_used), _ptr(linv), flags, _stream_handle(),
         )
     _lib.check_rc(rc, "scaml_gp_fit_fused_f64")
-    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used)
+    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used, Linv_diag=linv)
+
+
+def source_posteriors(
+    Xq: torch.Tensor,
+    X: torch.Tensor,
+    theta: torch.Tensor,
+    kind: int,
+    L: torch.Tensor,
+    Linv_diag: torch.Tensor,
+    alpha: torch.Tensor,
+    y_mean: Optional[torch.Tensor] = None,
+    y_std: Optional[torch.Tensor] = None,
+    n_points: Optional[torch.Tensor] = None,
+    want_var: bool = True,
+    cov_first: int = 0,
+) -> Dict[str, torch.Tensor]:
+    """Posteriors of all source GPs at the shared query points Xq (M, D).
+
+    Returns dict(mean (T, M), var (T, M) or None, cov (T, cov_first, M) or None): ``cov`` is the
+    posterior covariance between the first ``cov_first`` query points and all of them (put the
+    target's training points first to get Sigma_nn and Sigma_nq in one go).  Un-standardised with
+    y_mean / y_std (T) when given.  Launches scaml_posterior_batched_f64 (+ scaml_posterior_cov_f64).
+    """
+    if X.dim() != 3 or Xq.dim() != 2:
+        raise ValueError("X must be (T, N, D) and Xq (M, D)")
+    T, N, D = X.shape
+    M = Xq.shape[0]
+    if Xq.shape[1] != D:
+        raise ValueError("Xq and X disagree on D")
+    X = _check(X, "X")
+    Xq = _check(Xq, "Xq")
+    theta = _check(theta, "theta", (T, D + 2))
+    L = _check(L, "L", (T, N, N))
+    Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
+    alpha = _check(alpha, "alpha", (T, N))
+    if y_mean is not None:
+        y_mean = _check(y_mean, "y_mean", (T,))
+    if y_std is not None:
+        y_std = _check(y_std, "y_std", (T,))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    if not 0 <= cov_first <= M:
+        raise ValueError("cov_first must be within [0, M]")
+    dev = X.device
+    with torch.cuda.device(dev):
+        mu = torch.empty((T, M), dtype=torch.float64, device=dev)
+        var = torch.empty((T, M), dtype=torch.float64, device=dev) if want_var else None
+        V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if cov_first > 0 else None
+        rc = _lib.lib.scaml_posterior_batched_f64(
+            _ptr(Xq), _ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(y_mean), _ptr(y_std),
+            _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), _stream_handle())
+        _lib.check_rc(rc, "scaml_posterior_batched_f64")
+        cov = None
+        if cov_first > 0:
+            cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)
+            rc = _lib.lib.scaml_posterior_cov_f64(_ptr(Xq), _ptr(theta), _ptr(V), _ptr(y_std), T, N, M, cov_first, D,
+                                                  int(kind), _ptr(cov), _stream_handle())
+            _lib.check_rc(rc, "scaml_posterior_cov_f64")
+    return dict(mean=mu, var=var, cov=cov)
+
+
+def weighted_task_sum(values: torch.Tensor, weights: torch.Tensor, power: int = 1,
+                      active: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_t w_t^power * values[t] over the task axis (dim 0), optionally only over active tasks
+    (bool mask, scamlgp/model.py:368-372).  Launches scaml_weighted_task_sum_f64."""
+    T = values.shape[0]
+    values = _check(values, "values")
+    weights = _check(weights, "weights", (T,))
+    if active is not None:
+        if not active.is_cuda or active.shape != (T,):
+            raise ValueError("active must be a (T,) GPU tensor")
+        active = active.to(torch.uint8).contiguous()
+    out = torch.empty(values.shape[1:], dtype=torch.float64, device=values.device)
+    with torch.cuda.device(values.device):
+        rc = _lib.lib.scaml_weighted_task_sum_f64(_ptr(values), _ptr(weights), _ptr(active), T, out.numel(), int(power),
+                                                  _ptr(out), _stream_handle())
+    _lib.check_rc(rc, "scaml_weighted_task_sum_f64")
+    return out
 
 
 def raise_if_not_psd(info: torch.Tensor) -> None:

@@ -35,16 +35,16 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     f = _lib.lib.scaml_gp_fit_fused_f64
     one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
     # NULL X
-    assert f(None, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, one, None, 0, None) == _lib.E_BADARG
+    assert f(None, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, one, None, None, 0, None) == _lib.E_BADARG
     # NULL info
-    assert f(one, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, None, None, 0, None) == _lib.E_BADARG
+    assert f(one, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, None, None, None, 0, None) == _lib.E_BADARG
     # STORE_L without L
-    assert f(one, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, one, None, _lib.FIT_STORE_L, None) == _lib.E_BADARG
+    assert f(one, one, one, None, None, 1, 8, 2, 0, None, None, None, None, None, one, None, None, _lib.FIT_STORE_L, None) == _lib.E_BADARG
     # unknown kernel kind
-    assert f(one, one, one, None, None, 1, 8, 2, 7, None, None, None, None, None, one, None, 0, None) == _lib.E_BADARG
+    assert f(one, one, one, None, None, 1, 8, 2, 7, None, None, None, None, None, one, None, None, 0, None) == _lib.E_BADARG
     # N too large for the register-resident kernel
-    assert f(one, one, one, None, None, 1, 100000, 2, 0, None, None, None, None, None, one, None, 0, None) == _lib.E_TOOLARGE
+    assert f(one, one, one, None, None, 1, 100000, 2, 0, None, None, None, None, None, one, None, None, 0, None) == _lib.E_TOOLARGE
     # D too large for the LDS budget
-    assert f(one, one, one, None, None, 1, 256, 5000, 0, None, None, None, None, None, one, None, 0, None) == _lib.E_TOOLARGE
+    assert f(one, one, one, None, None, 1, 256, 5000, 0, None, None, None, None, None, one, None, None, 0, None) == _lib.E_TOOLARGE
     # empty stack is a no-op
-    assert f(one, one, one, None, None, 0, 8, 2, 0, None, None, None, None, None, one, None, 0, None) == 0
+    assert f(one, one, one, None, None, 0, 8, 2, 0, None, None, None, None, None, one, None, None, 0, None) == 0

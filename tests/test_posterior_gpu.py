@@ -1,0 +1,101 @@
+"""GPU parity tests for the batched source posterior (scaml_posterior_batched_f64 /
+scaml_posterior_cov_f64) and the weighted task sum (scaml_weighted_task_sum_f64).
+Tolerance (north_star): 1e-4 relative on posterior mean / variance."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as O
+from scamlgp_amd import ops, synthetic
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+RTOL = 1e-4
+
+
+def _fit(X, y, theta, kind, device, n_points=None):
+    return ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, n_points=n_points, want_linv=True)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_posterior_matches_golden(path, device):
+    g = np.load(path)
+    if (g["jitter"] > 0).any():
+        pytest.skip("jitter-rescued tasks are ill-conditioned by construction; covered by the fit tests")
+    kind = int(g["kind"])
+    X, y, theta, xq = (torch.from_numpy(g[k]) for k in ("X", "y", "theta", "xq"))
+    ragged = bool((g["n_points"] != X.shape[1]).any())
+    npts = torch.from_numpy(g["n_points"]).to(device) if ragged else None
+    fit = _fit(X, y, theta, kind, device, npts)
+    M = xq.shape[0]
+    post = ops.source_posteriors(xq.to(device), X.to(device), theta.to(device), kind, fit["L"], fit["Linv_diag"], fit["alpha"],
+                                 torch.from_numpy(g["y_mean"]).to(device), torch.from_numpy(g["y_std"]).to(device),
+                                 n_points=npts, cov_first=M)
+    mean, var, cov = (post[k].cpu().numpy() for k in ("mean", "var", "cov"))
+    scale = np.abs(g["post_cov"]).max(axis=(1, 2), keepdims=True)
+    np.testing.assert_allclose(mean, g["post_mean"], rtol=RTOL, atol=RTOL * np.abs(g["post_mean"]).max())
+    np.testing.assert_allclose(cov, g["post_cov"], rtol=0, atol=RTOL * scale.max())
+    np.testing.assert_allclose(var, np.diagonal(g["post_cov"], axis1=1, axis2=2), rtol=0, atol=RTOL * scale.max())
+
+
+@pytest.mark.parametrize("T,N,D,M,kind", [
+    (3, 32, 2, 7, O.KIND_RBF),
+    (4, 100, 5, 33, O.KIND_MATERN52),
+    (2, 256, 8, 80, O.KIND_MATERN52),
+    (5, 128, 3, 200, O.KIND_RBF),
+])
+def test_posterior_matches_oracle(T, N, D, M, kind, device):
+    d = synthetic.smooth_field_task_stack(T, N, D, seed=3 + N)
+    ys, m, s = synthetic.standardize_rows(d["Y"])
+    rng = np.random.default_rng(N)
+    theta = torch.from_numpy(np.concatenate([0.5 * (1 + 0.4 * (rng.uniform(size=(T, D)) - 0.5)), np.ones((T, 1)), np.full((T, 1), 1e-3)], 1))
+    X, y = torch.from_numpy(d["X"]), torch.from_numpy(ys)
+    xq = torch.from_numpy(rng.uniform(size=(M, D)))
+    fit = _fit(X, y, theta, kind, device)
+    Ma = min(M, 20)
+    post = ops.source_posteriors(xq.to(device), X.to(device), theta.to(device), kind, fit["L"], fit["Linv_diag"], fit["alpha"],
+                                 torch.from_numpy(m).to(device), torch.from_numpy(s).to(device), cov_first=Ma)
+    for t in range(T):
+        ref = O.gp_fit(X[t], y[t], theta[t], kind)
+        mu, cov = O.source_posterior(xq, X[t], theta[t], kind, ref["L"], ref["alpha"], float(m[t]), float(s[t]))
+        scale = float(cov.abs().max())
+        torch.testing.assert_close(post["mean"][t].cpu(), mu, rtol=RTOL, atol=RTOL * float(mu.abs().max()))
+        torch.testing.assert_close(post["var"][t].cpu(), cov.diagonal(), rtol=0, atol=RTOL * scale)
+        torch.testing.assert_close(post["cov"][t].cpu(), cov[:Ma], rtol=0, atol=RTOL * scale)
+        # tight check against the same distance formulation
+        mu_d, cov_d = O.source_posterior(xq, X[t], theta[t], kind, ref["L"], ref["alpha"], float(m[t]), float(s[t]), dist="direct")
+        torch.testing.assert_close(post["mean"][t].cpu(), mu_d, rtol=1e-8, atol=1e-9 * float(mu.abs().max()))
+
+
+def test_posterior_at_training_points_collapses(device):
+    # at the training inputs the posterior variance is bounded by the noise level and the mean
+    # reproduces the (standardised) data up to the noise shrinkage
+    T, N, D = 2, 64, 2
+    d = synthetic.branin_task_stack(T, N, seed=11, noise_std=0.0)
+    ys, m, s = synthetic.standardize_rows(d["Y"])
+    theta = torch.tensor([[0.3, 0.3, 1.0, 1e-6]] * T, dtype=torch.float64)
+    X, y = torch.from_numpy(d["X"]), torch.from_numpy(ys)
+    fit = _fit(X, y, theta, O.KIND_RBF, device)
+    post = ops.source_posteriors(X[0].to(device), X.to(device), theta.to(device), O.KIND_RBF, fit["L"], fit["Linv_diag"], fit["alpha"])
+    assert float(post["var"][0].max()) < 1e-5 and float(post["var"][0].min()) > -1e-9
+    torch.testing.assert_close(post["mean"][0].cpu(), y[0], rtol=0, atol=2e-2)
+
+
+def test_weighted_task_sum_and_pruning_mask(device):
+    T, M = 6, 37
+    g = torch.Generator().manual_seed(0)
+    mus = torch.randn(T, M, dtype=torch.float64, generator=g)
+    covs = torch.randn(T, 5, M, dtype=torch.float64, generator=g)
+    w = torch.tensor([0.5, 1e-7, 0.3, 0.0, 0.9, 0.2], dtype=torch.float64)
+    stds = torch.tensor([1.0, 2.0, 0.5, 1.0, 1.5, 0.1], dtype=torch.float64)
+    mask = O.significant_weights_mask(w, stds, 1e-3)
+    mu_ref, cov_ref = O.target_prior(mus, covs.reshape(T, -1), w, mask)
+    mu = ops.weighted_task_sum(mus.to(device), w.to(device), 1, mask.to(device))
+    cov = ops.weighted_task_sum(covs.to(device), w.to(device), 2, mask.to(device))
+    torch.testing.assert_close(mu.cpu(), mu_ref, rtol=1e-14, atol=1e-15)
+    torch.testing.assert_close(cov.cpu().reshape(-1), cov_ref, rtol=1e-14, atol=1e-15)
+    torch.testing.assert_close(ops.weighted_task_sum(mus.to(device), w.to(device)).cpu(), (w[:, None] * mus).sum(0))

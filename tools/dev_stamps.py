@@ -6,7 +6,7 @@ import numpy as np, torch
 from scamlgp_amd import synthetic
 lib = ctypes.CDLL(os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd", "lib", "libscaml_hip_stamps.so"))
 vp = ctypes.c_void_p
-lib.scaml_gp_fit_fused_f64.argtypes = [vp]*5 + [ctypes.c_int]*4 + [vp]*7 + [ctypes.c_uint, vp]
+lib.scaml_gp_fit_fused_f64.argtypes = [vp]*5 + [ctypes.c_int]*4 + [vp]*8 + [ctypes.c_uint, vp]
 lib.scaml_debug_set_stamp_buffer.argtypes = [vp]
 T, N, D = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 256, int(sys.argv[3]) if len(sys.argv) > 3 else 8
 kind = int(sys.argv[4]) if len(sys.argv) > 4 else 1
@@ -20,7 +20,7 @@ q, ld, mll, jit = (torch.empty(T, dtype=torch.float64, device=dev) for _ in rang
 stamps = torch.zeros(T, 2, 16, dtype=torch.int64, device=dev)
 assert lib.scaml_debug_set_stamp_buffer(stamps.data_ptr()) == 0
 for _ in range(3):
-    rc = lib.scaml_gp_fit_fused_f64(X.data_ptr(), y.data_ptr(), th.data_ptr(), None, None, T, N, D, kind, L.data_ptr(), alpha.data_ptr(), q.data_ptr(), ld.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(), 3, None)
+    rc = lib.scaml_gp_fit_fused_f64(X.data_ptr(), y.data_ptr(), th.data_ptr(), None, None, T, N, D, kind, L.data_ptr(), alpha.data_ptr(), q.data_ptr(), ld.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(), None, 3, None)
     assert rc == 0
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
