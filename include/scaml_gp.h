@@ -112,6 +112,22 @@ int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double*
 int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t* active, int T, long long len,
                                 int power, double* out, void* stream);
 
+/*
+ * (4) Analytic gradient of mll[t] (as defined for scaml_gp_fit_fused_f64, no prior terms) w.r.t. the
+ * constrained hyper-parameters theta[t] = [l_0..l_{D-1}, os, noise].  Replaces the autograd pass of
+ * botorch's fit_gpytorch_mll through kernel, Cholesky and solve (scamlgp/utils.py:175, 190).
+ *   d mll / d theta_p = (1 / 2 n_t) sum_ij (alpha alpha^T - K^-1)_ij dK_ij / d theta_p.
+ * Inputs are the X, theta and the L, Linv_diag, alpha produced by the fused fit.  `workspace` must
+ * hold scaml_mll_backward_workspace_doubles(T, N, D) doubles (L^-1 per task, then per-tile partial
+ * sums).  Result: partial sums (T, tiles, D+2), tiles = nb (nb+1)/2 with nb = ceil(N/16), written
+ * to `partials_out` if given, else to the tail of the workspace; the caller adds them over the tile
+ * axis and divides by 2 n_t (deterministic: no atomics).
+ */
+long long scaml_mll_backward_workspace_doubles(int T, int N, int D);
+int scaml_mll_backward_f64(const double* X, const double* theta, const double* L, const double* Linv_diag,
+                           const double* alpha, const int32_t* n_points, int T, int N, int D, int kind,
+                           double* workspace, double* partials_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

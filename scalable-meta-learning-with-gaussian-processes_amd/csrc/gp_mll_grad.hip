@@ -1,0 +1,173 @@
+// gp_mll_grad.hip — analytic gradient of the (un-priored) marginal log-likelihood w.r.t. the
+// constrained hyper-parameters [lengthscales, outputscale, noise] for a stack of tasks (gfx950).
+//
+// Replaces the autograd pass through kernel -> Cholesky -> solve that botorch's
+// fit_gpytorch_mll runs per L-BFGS-B iteration (scamlgp/utils.py:175, 190):
+//   mll = -(y^T K^-1 y + log|K| + n log 2pi) / (2n)
+//   d mll / d theta_p = (1 / 2n) sum_ij G_ij dK_ij/dtheta_p,   G = alpha alpha^T - K^-1.
+// Two kernels: (1) Linv = L^-1 by the same blocked MFMA substitution as the posterior kernel with an
+// identity right-hand side (only row blocks at or below the strip are touched); (2) per 16x16 tile
+// of the lower triangle: K^-1 tile = Linv^T Linv on the matrix cores, then the lanes re-evaluate the
+// kernel derivatives for the elements they own and reduce G o dK into D + 2 partial sums per tile
+// (off-diagonal tiles count twice).  Partial sums go to a (T, tiles, D+2) buffer that the caller
+// adds up (deterministic, no atomics).
+#include "scaml_common.hpp"
+#include "../../include/scaml_gp.h"
+#include "gp_posterior_params.h"
+
+namespace scaml {
+
+__global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
+  extern __shared__ double lds[];
+  const int N = p.N, NB = (N + 15) / 16, NP = NB * 16;
+  const int task = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  int n = p.n_points ? p.n_points[task] : N;
+  n = n < 0 ? 0 : (n > N ? N : n);
+  double* Vs = lds + (size_t)wave * NP * 16;
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * NB * 256;
+  double* Og = p.Linv + (size_t)task * N * N;
+  const int strip = blockIdx.x * nwaves + wave;
+  if (strip >= NB) return;
+  const int qc = 16 * strip + lc;  // column of the inverse owned by this lane
+  // rows above the strip are zero
+  for (int r = lq; r < 16 * strip && r < N; r += 4)
+    if (qc < N) Og[(size_t)r * N + qc] = 0.0;
+  for (int kb = strip; kb < NB; ++kb) {
+    d4_t acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = (kb == strip && lc == lq + 4 * g) ? 1.0 : 0.0;
+    const int arow = 16 * kb + lc;
+    const bool arow_ok = arow < n;
+    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
+    for (int j = strip; j < kb; ++j) {
+      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int col = 16 * j + 4 * m + lq;
+        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
+      }
+    }
+    d4_t v = {0.0, 0.0, 0.0, 0.0};
+    const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + lq + 4 * g;
+      Vs[row * 16 + lc] = v[g];
+      if (row < N && qc < N) Og[(size_t)row * N + qc] = v[g];
+    }
+  }
+}
+
+// kernel value k (without outputscale) and h with dk/dl_d = h * delta_d^2 / l_d^3
+template <int KIND>
+__device__ __forceinline__ void kernel_and_dfactor(double d2, const double* exptab, double& k, double& h) {
+  if (KIND == 0) {
+    k = exp_neg(-0.5 * d2, exptab);
+    h = k;
+  } else {
+    double dd = d2 < 1e-30 ? 1e-30 : d2;
+    dd = dd > 1e30 ? 1e30 : dd;
+    const double r = sqrt_from_rinv(dd, rsqrt_seeded(dd));
+    const double s5 = 2.2360679774997896964;
+    const double e = exp_neg(-s5 * r, exptab);
+    k = __builtin_fma(__builtin_fma(r, 5.0 / 3.0, s5), r, 1.0) * e;
+    h = (5.0 / 3.0) * __builtin_fma(s5, r, 1.0) * e;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
+  __shared__ double exptab[64];
+  const int N = p.N, D = p.D, NB = (N + 15) / 16;
+  const int task = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  exp2_table_init(exptab, tid);
+  __syncthreads();
+  const int NT = NB * (NB + 1) / 2;
+  const int tile = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (tile >= NT) return;
+  // tile -> (ta >= tc), column-major over the lower triangle
+  int tc = 0, off = 0;
+  while (tc < NB - 1 && off + (NB - tc) <= tile) { off += NB - tc; ++tc; }
+  const int ta = tc + (tile - off);
+  int n = p.n_points ? p.n_points[task] : N;
+  n = n < 0 ? 0 : (n > N ? N : n);
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double os = th[D];
+  const double* Xg = p.X + (size_t)task * N * D;
+  const double* al = p.alpha + (size_t)task * N;
+  const double* Li = p.Linv + (size_t)task * N * N;
+  // K^-1 tile: sum_r Linv[r][a] Linv[r][c], r >= 16 ta (Linv is lower triangular, a >= c)
+  const int pa = 16 * ta + lc, pc = 16 * tc + lc;
+  d4_t kin = {0.0, 0.0, 0.0, 0.0};
+  for (int r0 = 16 * ta; r0 < N; r0 += 4) {
+    const int r = r0 + lq;
+    const double a = (r < N && pa < N) ? Li[(size_t)r * N + pa] : 0.0;
+    const double b = (r < N && pc < N) ? Li[(size_t)r * N + pc] : 0.0;
+    kin = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, kin, 0, 0, 0);
+  }
+  // epilogue: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc
+  const double wgt = ta == tc ? 1.0 : 2.0;
+  double g_os = 0.0, g_noise = 0.0;
+  double* outp = p.partials + ((size_t)task * NT + tile) * (D + 2);
+  const double ac = pc < n ? al[pc] : 0.0;
+  double G[4], hk[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int a = 16 * ta + lq + 4 * g;
+    const bool ok = a < n && pc < n;
+    double d2 = 0.0;
+    if (ok) {
+      for (int d = 0; d < D; ++d) {
+        const double df = (Xg[(size_t)a * D + d] - Xg[(size_t)pc * D + d]) / th[d];
+        d2 = __builtin_fma(df, df, d2);
+      }
+    }
+    double k, h;
+    kernel_and_dfactor<KIND>(d2, exptab, k, h);
+    const double Gv = ok ? wgt * (al[a] * ac - kin[g]) : 0.0;
+    G[g] = Gv;
+    hk[g] = h;
+    g_os = __builtin_fma(Gv, k, g_os);
+    if (a == pc) g_noise += Gv;
+  }
+  // lengthscales: sum G os h delta_d^2 / l_d^3
+  for (int d = 0; d < D; ++d) {
+    const double l = th[d];
+    const double il3 = 1.0 / (l * l * l);
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int a = 16 * ta + lq + 4 * g;
+      if (a < n && pc < n) {
+        const double df = Xg[(size_t)a * D + d] - Xg[(size_t)pc * D + d];
+        s = __builtin_fma(G[g] * hk[g], df * df, s);
+      }
+    }
+    s *= os * il3;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) outp[d] = s;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    g_os += __shfl_xor(g_os, o);
+    g_noise += __shfl_xor(g_noise, o);
+  }
+  if (lane == 0) {
+    outp[D] = g_os;        // = sum G k  (d K / d os = k)
+    outp[D + 1] = g_noise; // = tr G
+  }
+}
+
+}  // namespace scaml
+
+template __global__ void scaml::gp_mll_grad_kernel<0>(scaml::MllGradParams);
+template __global__ void scaml::gp_mll_grad_kernel<1>(scaml::MllGradParams);

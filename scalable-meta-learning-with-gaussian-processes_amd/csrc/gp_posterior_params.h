@@ -30,4 +30,22 @@ struct PosteriorCovParams {
   int T, N, M, Ma, D;
 };
 
+struct LinvParams {
+  const double* L;          // (T, N, N)
+  const double* Linv_diag;  // (T, ceil(N/16), 16, 16)
+  const int32_t* n_points;  // (T) or NULL
+  double* Linv;             // (T, N, N) out: L^-1 (dense, zero above the diagonal)
+  int T, N;
+};
+
+struct MllGradParams {
+  const double* X;          // (T, N, D)
+  const double* theta;      // (T, D+2)
+  const double* alpha;      // (T, N)
+  const double* Linv;       // (T, N, N)
+  const int32_t* n_points;  // (T) or NULL
+  double* partials;         // (T, tiles, D+2), tiles = nb (nb + 1) / 2, nb = ceil(N/16)
+  int T, N, D;
+};
+
 }  // namespace scaml

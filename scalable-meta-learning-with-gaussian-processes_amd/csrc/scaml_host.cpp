@@ -42,6 +42,8 @@ struct Module {
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t wsum = nullptr;
+  hipFunction_t linv = nullptr;
+  hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
     if (loaded) return hipSuccess;
@@ -67,6 +69,13 @@ struct Module {
       if ((e = hipModuleGetFunction(&post_cov[kind], mod, name)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
+    if ((e = hipModuleGetFunction(&linv, mod, "_ZN5scaml14gp_linv_kernelENS_10LinvParamsE")) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)linv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      snprintf(name, sizeof(name), "_ZN5scaml18gp_mll_grad_kernelILi%dEEEvNS_13MllGradParamsE", kind);
+      if ((e = hipModuleGetFunction(&mllgrad[kind], mod, name)) != hipSuccess) return e;
+    }
     loaded = true;
     return hipSuccess;
   }
@@ -202,6 +211,45 @@ int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t
   void* args[] = {(void*)&in, (void*)&w, (void*)&active, (void*)&T, (void*)&len, (void*)&power, (void*)&out};
   e = hipModuleLaunchKernel(m.wsum, (unsigned)((len + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(weighted_task_sum)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+// ---- (4) gradient of the marginal log-likelihood ------------------------------------------------
+long long scaml_mll_backward_workspace_doubles(int T, int N, int D) {
+  const long long nb = (N + 15) / 16;
+  return (long long)T * N * N + (long long)T * (nb * (nb + 1) / 2) * (D + 2);
+}
+
+int scaml_mll_backward_f64(const double* X, const double* theta, const double* L, const double* Linv_diag,
+                           const double* alpha, const int32_t* n_points, int T, int N, int D, int kind,
+                           double* workspace, double* partials_out, void* stream) {
+  if (T < 0 || N < 1 || D < 1) return SCAML_E_BADARG;
+  if (!X || !theta || !L || !Linv_diag || !alpha || !workspace) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  const int nb = (N + 15) / 16, np = nb * 16, nt = nb * (nb + 1) / 2;
+  double* Linv = workspace;
+  double* partials = partials_out ? partials_out : workspace + (size_t)T * N * N;
+  int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
+  {
+    scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N};
+    size_t psize = sizeof(p);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+    e = hipModuleLaunchKernel(m.linv, (unsigned)((nb + waves - 1) / waves), (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
+                              (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
+    if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_linv)", e); return SCAML_E_LAUNCH; }
+  }
+  {
+    scaml::MllGradParams p{X, theta, alpha, Linv, n_points, partials, T, N, D};
+    size_t psize = sizeof(p);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+    e = hipModuleLaunchKernel(m.mllgrad[kind], (unsigned)((nt + 3) / 4), (unsigned)T, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+    if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad)", e); return SCAML_E_LAUNCH; }
+  }
   return SCAML_OK;
 }
 

@@ -72,6 +72,10 @@ def _load() -> ctypes.CDLL:
     lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]
     lib.scaml_weighted_task_sum_f64.restype = c_int
     lib.scaml_weighted_task_sum_f64.argtypes = [_dp, _dp, _dp, c_int, ctypes.c_longlong, c_int, _dp, c_void_p]
+    lib.scaml_mll_backward_workspace_doubles.restype = ctypes.c_longlong
+    lib.scaml_mll_backward_workspace_doubles.argtypes = [c_int, c_int, c_int]
+    lib.scaml_mll_backward_f64.restype = c_int
+    lib.scaml_mll_backward_f64.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, _dp, _dp, c_void_p]
     return lib
 
 
@@ -88,6 +92,8 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_batched_f64",
     "scaml_posterior_cov_f64",
     "scaml_weighted_task_sum_f64",
+    "scaml_mll_backward_workspace_doubles",
+    "scaml_mll_backward_f64",
 )
 
 

@@ -185,6 +185,39 @@ def weighted_task_sum(values: torch.Tensor, weights: torch.Tensor, power: int = 
     return out
 
 
+def mll_backward(
+    X: torch.Tensor,
+    theta: torch.Tensor,
+    kind: int,
+    L: torch.Tensor,
+    Linv_diag: torch.Tensor,
+    alpha: torch.Tensor,
+    n_points: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """d mll[t] / d theta[t] (T, D+2) for the constrained hyper-parameters, from the outputs of
+    ``gp_fit_fused(..., want_linv=True)``.  Launches scaml_mll_backward_f64; the final sum over the
+    per-tile partials and the 1 / (2 n_t) scaling are two tiny torch ops."""
+    T, N, D = X.shape
+    X = _check(X, "X")
+    theta = _check(theta, "theta", (T, D + 2))
+    L = _check(L, "L", (T, N, N))
+    Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
+    alpha = _check(alpha, "alpha", (T, N))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    nb = (N + 15) // 16
+    nt = nb * (nb + 1) // 2
+    dev = X.device
+    with torch.cuda.device(dev):
+        work = torch.empty((T * N * N,), dtype=torch.float64, device=dev)
+        partials = torch.empty((T, nt, D + 2), dtype=torch.float64, device=dev)
+        rc = _lib.lib.scaml_mll_backward_f64(_ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(n_points),
+                                             T, N, D, int(kind), _ptr(work), _ptr(partials), _stream_handle())
+    _lib.check_rc(rc, "scaml_mll_backward_f64")
+    n = n_points.to(torch.float64) if n_points is not None else torch.full((T,), float(N), dtype=torch.float64, device=dev)
+    return partials.sum(1) / (2.0 * n.clamp_min(1.0)).unsqueeze(-1)
+
+
 def raise_if_not_psd(info: torch.Tensor) -> None:
     """Host-side check of the per-task status (one device->host sync)."""
     bad = torch.nonzero(info > 0).flatten()
