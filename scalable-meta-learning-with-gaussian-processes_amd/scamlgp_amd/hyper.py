@@ -1,0 +1,254 @@
+"""Hyper-parameter plumbing of the GP stack: sigmoid-Interval re-parameterisation, priors, prior
+sampling and a batched L-BFGS that advances many independent problems with one objective call
+per iteration (one fused GPU launch for all tasks x restarts).
+
+Restates, without gpytorch/botorch, the pieces the reference takes from them:
+  scamlgp/model.py:25-33, 36-70, 73-105   constraints (Interval, sigmoid transform), initial values, priors
+  scamlgp/utils.py:31-69                  sample_all_priors (resample until the constraint's
+                                          inverse transform is finite, up to 5 retries)
+  scamlgp/utils.py:139-212                warm start + prior-sampled restarts, keep the best
+Plain torch only (runs on CPU or GPU tensors alike); no hot-path arithmetic lives here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Tuple
+
+import torch
+
+_LOG_2PI = math.log(2.0 * math.pi)
+
+
+# --- constraints -------------------------------------------------------------------------
+@dataclass(frozen=True)
+class Interval:
+    """gpytorch.constraints.Interval with the default sigmoid transform."""
+    lower: float
+    upper: float
+
+    def transform(self, raw: torch.Tensor) -> torch.Tensor:
+        return self.lower + (self.upper - self.lower) * torch.sigmoid(raw)
+
+    def inverse_transform(self, value: torch.Tensor) -> torch.Tensor:
+        p = (value - self.lower) / (self.upper - self.lower)
+        return torch.log(p) - torch.log1p(-p)
+
+    def dtransform(self, raw: torch.Tensor) -> torch.Tensor:
+        """d theta / d raw."""
+        s = torch.sigmoid(raw)
+        return (self.upper - self.lower) * s * (1.0 - s)
+
+
+# --- priors (log-densities on the constrained values, and samplers) -----------------------------
+@dataclass(frozen=True)
+class GammaPrior:
+    concentration: float
+    rate: float
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        c, r = self.concentration, self.rate
+        return c * math.log(r) + (c - 1.0) * torch.log(x) - r * x - math.lgamma(c)
+
+    def dlog_prob(self, x: torch.Tensor) -> torch.Tensor:
+        return (self.concentration - 1.0) / x - self.rate
+
+    def sample(self, shape, generator=None, dtype=torch.float64, device=None) -> torch.Tensor:
+        g = torch.distributions.Gamma(torch.tensor(self.concentration, dtype=dtype), torch.tensor(self.rate, dtype=dtype))
+        # torch.distributions draws from the global RNG (the reference seeds it: scamlgp/model.py:163-164)
+        return g.sample(shape).to(device)
+
+
+@dataclass(frozen=True)
+class LogNormalPrior:
+    loc: float
+    scale: float
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        lx = torch.log(x)
+        return -lx - math.log(self.scale) - 0.5 * _LOG_2PI - (lx - self.loc) ** 2 / (2.0 * self.scale ** 2)
+
+    def dlog_prob(self, x: torch.Tensor) -> torch.Tensor:
+        return -(1.0 + (torch.log(x) - self.loc) / self.scale ** 2) / x
+
+    def sample(self, shape, generator=None, dtype=torch.float64, device=None) -> torch.Tensor:
+        d = torch.distributions.LogNormal(torch.tensor(self.loc, dtype=dtype), torch.tensor(self.scale, dtype=dtype))
+        return d.sample(shape).to(device)
+
+
+@dataclass(frozen=True)
+class HyperSpec:
+    """Constraint + prior + initial value of the three hyper-parameter groups of one GP:
+    lengthscales (D values), outputscale, noise variance."""
+    ls_constraint: Interval
+    ls_prior: object
+    ls_init: float
+    os_constraint: Interval
+    os_prior: object
+    os_init: float
+    noise_constraint: Interval
+    noise_prior: object
+    noise_init: float
+
+    def constraints(self, D: int):
+        return [self.ls_constraint] * D + [self.os_constraint, self.noise_constraint]
+
+    def priors(self, D: int):
+        return [self.ls_prior] * D + [self.os_prior, self.noise_prior]
+
+    def bounds(self, D: int, dtype=torch.float64, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        lo = torch.tensor([c.lower for c in self.constraints(D)], dtype=dtype, device=device)
+        hi = torch.tensor([c.upper for c in self.constraints(D)], dtype=dtype, device=device)
+        return lo, hi
+
+    def init_theta(self, D: int, dtype=torch.float64, device=None) -> torch.Tensor:
+        return torch.tensor([self.ls_init] * D + [self.os_init, self.noise_init], dtype=dtype, device=device)
+
+    # vectorised over leading dims: theta (..., D+2)
+    def to_theta(self, raw: torch.Tensor) -> torch.Tensor:
+        lo, hi = self.bounds(raw.shape[-1] - 2, raw.dtype, raw.device)
+        return lo + (hi - lo) * torch.sigmoid(raw)
+
+    def to_raw(self, theta: torch.Tensor) -> torch.Tensor:
+        lo, hi = self.bounds(theta.shape[-1] - 2, theta.dtype, theta.device)
+        p = (theta - lo) / (hi - lo)
+        return torch.log(p) - torch.log1p(-p)
+
+    def dtheta_draw(self, raw: torch.Tensor) -> torch.Tensor:
+        lo, hi = self.bounds(raw.shape[-1] - 2, raw.dtype, raw.device)
+        s = torch.sigmoid(raw)
+        return (hi - lo) * s * (1.0 - s)
+
+    def log_prior(self, theta: torch.Tensor) -> torch.Tensor:
+        D = theta.shape[-1] - 2
+        return (self.ls_prior.log_prob(theta[..., :D]).sum(-1) + self.os_prior.log_prob(theta[..., D])
+                + self.noise_prior.log_prob(theta[..., D + 1]))
+
+    def dlog_prior(self, theta: torch.Tensor) -> torch.Tensor:
+        D = theta.shape[-1] - 2
+        return torch.cat([self.ls_prior.dlog_prob(theta[..., :D]), self.os_prior.dlog_prob(theta[..., D:D + 1]),
+                          self.noise_prior.dlog_prob(theta[..., D + 1:])], -1)
+
+    def sample_prior(self, shape, D: int, num_retries: int = 5, dtype=torch.float64, device=None) -> torch.Tensor:
+        """scamlgp/utils.py:31-69: draw every hyper-parameter from its prior; a draw whose inverse
+        constraint transform is not finite (outside the interval) is redrawn, at most
+        ``num_retries`` times, then a RuntimeError is raised."""
+        out = torch.empty(*shape, D + 2, dtype=dtype, device=device)
+        cons, pris = self.constraints(D), self.priors(D)
+        groups = [(slice(0, D), cons[0], pris[0]), (slice(D, D + 1), cons[D], pris[D]), (slice(D + 1, D + 2), cons[D + 1], pris[D + 1])]
+        for sl, con, pri in groups:
+            width = sl.stop - sl.start
+            s = pri.sample((*shape, width), dtype=dtype, device=device)
+            for attempt in range(num_retries + 1):
+                # a model's draw is valid when every element maps to a finite raw value
+                bad = ~torch.isfinite(con.inverse_transform(s)).all(-1, keepdim=True)
+                if not bool(bad.any()):
+                    break
+                if attempt == num_retries:
+                    raise RuntimeError(f"Sampling of a hyper-prior failed {num_retries} times. Please check the "
+                                       "compatibility between prior support and the constraint.")
+                s = torch.where(bad, pri.sample((*shape, width), dtype=dtype, device=device), s)
+            out[..., sl] = s
+        return out
+
+
+# reference defaults -----------------------------------------------------------------------------
+def source_gp_spec() -> HyperSpec:
+    """scamlgp/model.py:25-33 (likelihood) and :36-70 (_get_kernel_source_gp)."""
+    return HyperSpec(Interval(1e-4, 1e2), GammaPrior(3.0, 6.0), 0.5,
+                     Interval(1e-4, 1e2), GammaPrior(2.0, 0.15), 1.0,
+                     Interval(1e-8, 1e-2), LogNormalPrior(-8.0, 2.0), 1e-3)
+
+
+def target_gp_spec() -> HyperSpec:
+    """scamlgp/model.py:25-33 (likelihood) and :73-105 (_get_default_kernel)."""
+    return HyperSpec(Interval(1e-4, 1e2), LogNormalPrior(0.5, 1.5), 1.0,
+                     Interval(1e-4, 1e2), LogNormalPrior(-2.0, 3.0), 0.1,
+                     Interval(1e-8, 1e-2), LogNormalPrior(-8.0, 2.0), 1e-3)
+
+
+# --- batched L-BFGS -----------------------------------------------------------------------------
+@dataclass
+class LBFGSResult:
+    x: torch.Tensor          # (B, P) final points
+    f: torch.Tensor          # (B,) final objective values (minimised)
+    n_iter: int
+    n_eval: int
+    converged: torch.Tensor  # (B,) bool
+    failed: torch.Tensor     # (B,) bool: objective returned non-finite at the start
+
+
+def batched_lbfgs(fun: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]], x0: torch.Tensor,
+                  max_iter: int = 200, history: int = 10, gtol: float = 1e-5, ftol: float = 2.2e-9,
+                  c1: float = 1e-4, max_ls: int = 20) -> LBFGSResult:
+    """Minimise B independent functions of P variables at once.  ``fun(x)`` -> (f (B,), g (B, P))
+    evaluates all of them in one call (for the GP stack: one fused launch).  Two-loop L-BFGS with a
+    per-problem backtracking (Armijo) line search; problems whose trial value is not finite shrink
+    their step; stopping rules follow scipy's L-BFGS-B (projected-gradient ``gtol``, relative
+    decrease ``ftol``), which botorch's fit_gpytorch_mll drives in the reference
+    (scamlgp/utils.py:175).  No bounds: the raw parameters are unconstrained."""
+    x = x0.clone()
+    B, P = x.shape
+    f, g = fun(x)
+    n_eval = 1
+    failed = ~torch.isfinite(f) | ~torch.isfinite(g).all(-1)
+    f = torch.where(failed, torch.full_like(f, float("inf")), f)
+    g = torch.where(failed.unsqueeze(-1), torch.zeros_like(g), g)
+    S = torch.zeros(B, history, P, dtype=x.dtype, device=x.device)
+    Y = torch.zeros_like(S)
+    rho = torch.zeros(B, history, dtype=x.dtype, device=x.device)
+    valid = torch.zeros(B, history, dtype=torch.bool, device=x.device)
+    done = failed.clone()
+    it = 0
+    for it in range(1, max_iter + 1):
+        # two-loop recursion (newest pair at index 0)
+        q = g.clone()
+        alphas = []
+        for i in range(history):
+            a = torch.where(valid[:, i], rho[:, i] * (S[:, i] * q).sum(-1), torch.zeros_like(f))
+            q = q - a.unsqueeze(-1) * Y[:, i]
+            alphas.append(a)
+        ys = (S[:, 0] * Y[:, 0]).sum(-1)
+        yy = (Y[:, 0] * Y[:, 0]).sum(-1)
+        gamma = torch.where(valid[:, 0] & (yy > 0), ys / yy.clamp_min(1e-300), torch.ones_like(f))
+        r = gamma.unsqueeze(-1) * q
+        for i in reversed(range(history)):
+            b = torch.where(valid[:, i], rho[:, i] * (Y[:, i] * r).sum(-1), torch.zeros_like(f))
+            r = r + (alphas[i] - b).unsqueeze(-1) * S[:, i]
+        d = -r
+        gd = (g * d).sum(-1)
+        # not a descent direction (or first iteration): steepest descent, scaled like scipy's first step
+        bad_dir = ~(gd < 0)
+        d = torch.where(bad_dir.unsqueeze(-1), -g, d)
+        gd = torch.where(bad_dir, -(g * g).sum(-1), gd)
+        t = torch.where(valid[:, 0] & ~bad_dir, torch.ones_like(f), (1.0 / g.norm(dim=-1).clamp_min(1e-12)).clamp_max(1.0))
+        # backtracking line search, all problems in lockstep
+        accepted = done.clone()
+        x_new, f_new, g_new = x.clone(), f.clone(), g.clone()
+        for _ in range(max_ls):
+            trial = x + t.unsqueeze(-1) * d
+            ft, gt = fun(torch.where(accepted.unsqueeze(-1), x, trial))
+            n_eval += 1
+            ok = torch.isfinite(ft) & torch.isfinite(gt).all(-1) & (ft <= f + c1 * t * gd) & ~accepted
+            x_new = torch.where(ok.unsqueeze(-1), trial, x_new)
+            f_new = torch.where(ok, ft, f_new)
+            g_new = torch.where(ok.unsqueeze(-1), gt, g_new)
+            accepted = accepted | ok
+            if bool(accepted.all()):
+                break
+            t = torch.where(accepted, t, 0.5 * t)
+        stalled = ~accepted  # line search failed: stop this problem where it is
+        s_vec = x_new - x
+        y_vec = g_new - g
+        sy = (s_vec * y_vec).sum(-1)
+        upd = (sy > 1e-10 * y_vec.norm(dim=-1) * s_vec.norm(dim=-1)) & ~done & ~stalled
+        S = torch.where(upd[:, None, None], torch.cat([s_vec.unsqueeze(1), S[:, :-1]], 1), S)
+        Y = torch.where(upd[:, None, None], torch.cat([y_vec.unsqueeze(1), Y[:, :-1]], 1), Y)
+        rho = torch.where(upd[:, None], torch.cat([(1.0 / sy.clamp_min(1e-300)).unsqueeze(1), rho[:, :-1]], 1), rho)
+        valid = torch.where(upd[:, None], torch.cat([torch.ones_like(upd).unsqueeze(1), valid[:, :-1]], 1), valid)
+        rel = (f - f_new) / torch.maximum(torch.maximum(f.abs(), f_new.abs()), torch.ones_like(f))
+        x, f_prev, f, g = x_new, f, f_new, g_new
+        done = done | stalled | (g.abs().amax(-1) <= gtol) | ((rel <= ftol) & ~stalled & (it > 1))
+        if bool(done.all()):
+            break
+    return LBFGSResult(x=x, f=f, n_iter=it, n_eval=n_eval, converged=done & ~failed, failed=failed)

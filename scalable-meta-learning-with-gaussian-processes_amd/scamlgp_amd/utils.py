@@ -1,0 +1,137 @@
+"""Host-side mirror of ``scamlgp/utils.py``: marginal-likelihood fitting with restarts and the
+acquisition functions, on top of the batched GPU path.
+
+  optimize_marginal_likelihood   scamlgp/utils.py:139-212  (warm start + ``num_restarts`` prior
+                                 samples, keep the best state, ModelFittingError if all failed)
+  UpperConfidenceBound           scamlgp/utils.py:215-224  (beta = 9, maximize=False)
+  ExpectedImprovement            scamlgp/optimizer.py:96-98 (botorch analytic EI, minimisation)
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Dict, Union
+
+import numpy as np
+import scipy.optimize
+import torch
+
+from . import hyper
+from .model import ScaMLGP, SourceGP, SourceGPStack
+
+logger = logging.getLogger("scamlgp_amd")
+
+
+class ModelFittingError(RuntimeError):
+    """All optimisation attempts failed (mirrors botorch.exceptions.ModelFittingError)."""
+
+
+def _fit_stack(stack: SourceGPStack, num_restarts: int, max_iter: int = 200) -> None:
+    """All T tasks x (1 + num_restarts) starts as ONE batch: every L-BFGS iteration is one fused-fit
+    launch + one gradient launch over (1 + R) * T problems."""
+    T, D = stack.T, stack.D
+    reps = 1 + num_restarts
+    starts = [stack.raw.clone()]
+    for _ in range(num_restarts):
+        starts.append(stack.spec.to_raw(stack.spec.sample_prior((T,), D, device=stack.device)))
+    x0 = torch.cat(starts, 0)  # problem b = rep * T + task
+    res = hyper.batched_lbfgs(lambda r: stack.objective(r, reps), x0, max_iter=max_iter)
+    f = torch.where(res.failed | ~torch.isfinite(res.f), torch.full_like(res.f, float("inf")), res.f).reshape(reps, T)
+    best = f.argmin(0)
+    if bool(torch.isinf(f.min(0).values).any()):
+        bad = torch.nonzero(torch.isinf(f.min(0).values)).flatten().tolist()
+        raise ModelFittingError(
+            "Hyperparameter optimization failed for all attempts. Usually this indicates a problem with model's "
+            f"input data or hyperparameter priors definitions. (tasks {[stack.task_ids[i] for i in bad][:8]})")
+    n_failed = int(torch.isinf(f).sum())
+    if n_failed:
+        logger.warning("%d of %d hyper-parameter optimisation attempts failed and were skipped.", n_failed, f.numel())
+    stack.raw = res.x.reshape(reps, T, D + 2)[best, torch.arange(T, device=stack.device)].contiguous()
+    stack.refresh()
+    stack.last_fit_info = dict(n_iter=res.n_iter, n_eval=res.n_eval, objective=-f.min(0).values)
+
+
+def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200) -> None:
+    """Target GP: weights + kernel hyper-parameters by scipy L-BFGS-B (the weights carry the box bound
+    w >= 1e-10, scamlgp/model.py:334), objective and gradient from torch autograd on the device."""
+    if model.n == 0:
+        return
+    D2, T = model.raw_theta.numel(), model.T
+    bounds = [(None, None)] * D2 + [(model.weights_lower_bound, None)] * T
+
+    def fun(z: np.ndarray):
+        zt = torch.tensor(z, dtype=torch.float64, device=model.device, requires_grad=True)
+        try:
+            val = -model.mll(zt[:D2], zt[D2:])
+            (g,) = torch.autograd.grad(val, zt)
+        except RuntimeError:  # Cholesky failure somewhere in the line search
+            return float("inf"), np.zeros_like(z)
+        v = float(val.detach())
+        if not math.isfinite(v):
+            return float("inf"), np.zeros_like(z)
+        return v, g.cpu().numpy()
+
+    def run(z0: np.ndarray):
+        r = scipy.optimize.minimize(fun, z0, jac=True, method="L-BFGS-B", bounds=bounds, options=dict(maxiter=maxiter))
+        return r.x, float(r.fun)
+
+    best_val, best_state = float("inf"), model.state_dict()
+    z0 = torch.cat([model.raw_theta, model.raw_weights]).cpu().numpy()
+    for attempt in range(1 + num_restarts):
+        if attempt > 0:
+            th = model.spec.sample_prior((), model.raw_theta.numel() - 2, device=model.device)
+            w = model.weights_prior.sample((T,), device=model.device).clamp_min(model.weights_lower_bound)
+            z0 = torch.cat([model.spec.to_raw(th), w]).cpu().numpy()
+        z, val = run(z0)
+        if math.isfinite(val) and val < best_val:
+            best_val = val
+            zt = torch.tensor(z, dtype=torch.float64, device=model.device)
+            best_state = {"raw_theta": zt[:D2].clone(), "raw_weights": zt[D2:].clone()}
+        elif not math.isfinite(val):
+            logger.warning("Error occurred while optimizing the model hyperparameters; this restart will be skipped.")
+    if not math.isfinite(best_val):
+        raise ModelFittingError("Hyperparameter optimization failed for all attempts. Usually this indicates a problem with "
+                                "model's input data or hyperparameter priors definitions.")
+    model.load_state_dict(best_state)
+
+
+def optimize_marginal_likelihood(model: Union[SourceGPStack, ScaMLGP, Dict, SourceGP], num_restarts: int = 0, **fit_options):
+    """Refit the model's hyper-parameters by maximising the marginal log likelihood (+ priors) on its
+    training data: once warm-started from the current parameters, ``num_restarts`` times from prior
+    samples; the best state is kept (scamlgp/utils.py:139-212)."""
+    if isinstance(model, dict):
+        model = list(model.values())[0]
+    if isinstance(model, SourceGP):
+        model = model._stack
+    if isinstance(model, SourceGPStack):
+        return _fit_stack(model, num_restarts, **fit_options)
+    if isinstance(model, ScaMLGP):
+        return _fit_target(model, num_restarts, **fit_options)
+    raise TypeError(f"cannot fit a {type(model).__name__}")
+
+
+# --- acquisition functions (to be MAXIMISED, for minimising the objective) -------------------------
+class UpperConfidenceBound:
+    """botorch UpperConfidenceBound(model, beta=9.0, maximize=False): value = -mu + sqrt(beta * var)."""
+
+    def __init__(self, model: ScaMLGP, beta: float = 9.0):
+        self.model, self.beta = model, beta
+
+    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        p = self.model.posterior(X)
+        return -p.mean + torch.sqrt(self.beta * p.variance.clamp_min(0.0))
+
+
+class ExpectedImprovement:
+    """botorch analytic ExpectedImprovement(model, best_f, maximize=False)."""
+
+    def __init__(self, model: ScaMLGP, best_f: float):
+        self.model, self.best_f = model, best_f
+
+    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        p = self.model.posterior(X)
+        sigma = p.variance.clamp_min(1e-9).sqrt()
+        u = -(p.mean - self.best_f) / sigma
+        pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+        cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+        return sigma * (pdf + u * cdf)

@@ -1,0 +1,157 @@
+"""GPU tests of the host model layer (scamlgp_amd.model / utils / bo) against the oracle."""
+import math
+
+import numpy as np
+import pytest
+import scipy.optimize
+import torch
+
+from oracle import gp_oracle as O
+from scamlgp_amd import hyper, model as M, synthetic, utils
+from scamlgp_amd.bo import ScaMLGPBOLoop
+
+pytestmark = pytest.mark.gpu
+
+
+def _meta_data(T, N, seed=0):
+    d = synthetic.branin_task_stack(T, N, seed=seed, noise_std=1.0)
+    return {f"task{t}": M.SupervisedDataset(torch.from_numpy(d["X"][t]), torch.from_numpy(d["Y"][t]).unsqueeze(-1)) for t in range(T)}, d
+
+
+@pytest.fixture(scope="module")
+def fitted(device):
+    meta, d = _meta_data(4, 32, seed=0)
+    gps = M.meta_fit_scamlgp(meta, num_restarts_log_likelihood=2, seed=1234)
+    return meta, d, gps
+
+
+def test_meta_fit_improves_objective_and_matches_scipy(fitted):
+    meta, d, gps = fitted
+    stack = gps["task0"]._stack
+    assert list(gps.keys()) == list(meta.keys())
+    theta = stack.theta.cpu()
+    lo, hi = stack.spec.bounds(2)
+    assert bool(((theta > lo) & (theta < hi)).all())
+    bounds = [(1e-4, 1e2)] * 3 + [(1e-8, 1e-2)]
+    raw0 = stack.spec.to_raw(stack.spec.init_theta(2))
+    for t in range(stack.T):
+        n = stack.n_list[t]
+        X, y = stack.X[t, :n].cpu(), stack.y[t, :n].cpu()
+        f_init, _, _ = O.mll_value_and_grad_raw(X, y, raw0, O.KIND_RBF, bounds)
+        f_ours, _, _ = O.mll_value_and_grad_raw(X, y, stack.raw[t].cpu(), O.KIND_RBF, bounds)
+        assert float(f_ours) >= float(f_init)
+        # an independent optimiser (scipy L-BFGS-B on the oracle) from the same init does not beat the batched fit
+        res = scipy.optimize.minimize(lambda z: tuple(map(lambda a: -a.numpy(), O.mll_value_and_grad_raw(X, y, torch.tensor(z), O.KIND_RBF, bounds)[:2])),
+                                      raw0.numpy(), jac=True, method="L-BFGS-B")
+        assert float(f_ours) >= -res.fun - 1e-4
+        # the cached objective equals the oracle's at the fitted hyper-parameters
+        np.testing.assert_allclose(float(stack.last_fit_info["objective"][t]), float(f_ours), rtol=1e-6)
+
+
+def test_validate_meta_data_errors():
+    with pytest.raises(ValueError, match="Empty meta data"):
+        M.validate_meta_data({})
+    a = M.SupervisedDataset(torch.rand(4, 2), torch.rand(4, 1))
+    b = M.SupervisedDataset(torch.rand(4, 3), torch.rand(4, 1))
+    with pytest.raises(ValueError, match="do not match"):
+        M.validate_meta_data({0: a, 1: b})
+    c = M.SupervisedDataset(torch.rand(4, 2), torch.rand(4, 2))
+    with pytest.raises(ValueError, match="must be one"):
+        M.validate_meta_data({0: a, 1: c})
+    assert a.X().shape == a.X.shape == (4, 2)
+
+
+def _oracle_prior(stack, idx, w, x):
+    mus, covs = [], []
+    for t in idx:
+        n = stack.n_list[t]
+        X, y, th = stack.X[t, :n].cpu(), stack.y[t, :n].cpu(), stack.theta[t].cpu()
+        fit = O.gp_fit(X, y, th, stack.kind)
+        mu, cov = O.source_posterior(x, X, th, stack.kind, fit["L"], fit["alpha"], float(stack.y_mean[t]), float(stack.y_std[t]))
+        mus.append(mu)
+        covs.append(cov)
+    return O.target_prior(torch.stack(mus), torch.stack(covs), w)
+
+
+def test_compute_target_prior_and_source_gp_views(fitted):
+    meta, d, gps = fitted
+    stack = gps["task0"]._stack
+    x = torch.rand(9, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    w = torch.tensor([0.3, 0.1, 0.7, 0.2], dtype=torch.float64)
+    mean, cov = M._compute_target_prior(x, list(gps.values()), w)
+    mu_ref, cov_ref = _oracle_prior(stack, range(4), w, x)
+    torch.testing.assert_close(mean.squeeze(-1).cpu(), mu_ref, rtol=1e-4, atol=1e-4 * float(mu_ref.abs().max()))
+    torch.testing.assert_close(cov.cpu(), cov_ref, rtol=0, atol=1e-4 * float(cov_ref.abs().max()))
+    with pytest.raises(ValueError, match="does not equal the number of weights"):
+        M._compute_target_prior(x, list(gps.values()), w[:2])
+    # subset of tasks
+    sub = [gps["task2"], gps["task0"]]
+    mean2, _ = M._compute_target_prior(x, sub, torch.tensor([0.5, 0.25], dtype=torch.float64))
+    mu2, _ = _oracle_prior(stack, [2, 0], torch.tensor([0.5, 0.25], dtype=torch.float64), x)
+    torch.testing.assert_close(mean2.squeeze(-1).cpu(), mu2, rtol=1e-4, atol=1e-4 * float(mu2.abs().max()))
+    # single-task view: posterior + outcome transform as the reference uses them (model.py:266, 281-288)
+    g = gps["task1"]
+    p = g.posterior(x)
+    assert p.mvn.mean.shape == (9,) and p.mvn.covariance_matrix.shape == (9, 9)
+    y_raw = g.outcome_transform.untransform(g.train_targets.unsqueeze(-1))[0]
+    np.testing.assert_allclose(y_raw.squeeze(-1).cpu().numpy(), d["Y"][1], rtol=1e-10, atol=1e-10)
+
+
+def test_scamlgp_train_forward_mll_and_posterior_match_oracle(fitted):
+    meta, d, gps = fitted
+    stack = gps["task0"]._stack
+    g = torch.Generator().manual_seed(5)
+    n = 7
+    Xt = torch.rand(n, 2, dtype=torch.float64, generator=g)
+    yt = torch.tensor(synthetic.branin(-5 + 15 * Xt[:, 0].numpy(), 15 * Xt[:, 1].numpy()), dtype=torch.float64).unsqueeze(-1)
+    model = M.ScaMLGP(Xt, yt, gps)
+    assert model.source_means.shape == (n, 4) and model.source_covs.shape == (n, n, 4)
+    assert model.weights.tolist() == [0.25] * 4
+    # Standardize over all meta + target data
+    Y_all = np.concatenate([d["Y"].reshape(-1), yt.squeeze(-1).numpy()])
+    np.testing.assert_allclose(float(model.m_all), Y_all.mean(), rtol=1e-10)
+    np.testing.assert_allclose(float(model.s_all), Y_all.std(ddof=1), rtol=1e-10)
+    w = torch.tensor([0.4, 0.05, 0.3, 0.6], dtype=torch.float64)
+    model.weights = w
+    theta_t = model.theta.cpu()
+    ref = O.target_train_mll(Xt, model.train_targets.cpu(), model.source_means.cpu(), model.source_covs.cpu(), w, theta_t, O.KIND_RBF,
+                             float(model.m_all), float(model.s_all))
+    np.testing.assert_allclose(float(model.mll()), float(ref), rtol=1e-6)
+    mvn = model.train().forward(Xt)
+    mean_ref = (model.source_means.cpu() @ w - float(model.m_all)) / float(model.s_all)
+    torch.testing.assert_close(mvn.mean.cpu(), mean_ref, rtol=1e-9, atol=1e-12)
+    # posterior vs the oracle's joint formulation (no task pruned with these weights)
+    xq = torch.rand(11, 2, dtype=torch.float64, generator=g)
+    post = model.eval().posterior(xq)
+    mu_j, cov_j = _oracle_prior(stack, range(4), w, torch.cat([Xt, xq]))
+    mu_ref, S_ref = O.target_posterior(xq, Xt, yt.squeeze(-1), mu_j, cov_j, theta_t, O.KIND_RBF, float(model.m_all), float(model.s_all))
+    torch.testing.assert_close(post.mean.cpu(), mu_ref, rtol=1e-4, atol=1e-4 * float(mu_ref.abs().max()))
+    torch.testing.assert_close(post.variance.cpu(), S_ref.diagonal(), rtol=1e-4, atol=1e-4 * float(S_ref.abs().max()))
+    # eval-mode forward prunes insignificant weights (model.py:364-375)
+    model.weights = torch.tensor([0.5, 1e-9, 0.5, 0.5], dtype=torch.float64)
+    ev = model.eval().forward(xq)
+    mu_p, cov_p = _oracle_prior(stack, [0, 2, 3], torch.tensor([0.5, 0.5, 0.5], dtype=torch.float64), xq)
+    torch.testing.assert_close(ev.mean.cpu(), (mu_p - float(model.m_all)) / float(model.s_all), rtol=1e-4, atol=1e-6)
+
+
+def test_target_fit_and_bo_loop_progress(fitted):
+    meta, d, gps = fitted
+    # target = a Branin family member on the unit square
+    def objective(x):
+        x = torch.as_tensor(x).reshape(-1)
+        return float(synthetic.branin(-5 + 15 * float(x[0]), 15 * float(x[1]), a=1.1, b=0.12, c=1.5, r=6.2, s=9.0, t=0.04))
+
+    loop = ScaMLGPBOLoop(gps, dim=2, num_restarts_log_likelihood=1, raw_samples=256, seed=0)
+    x0 = loop.suggest()          # works on an empty target data set (prior only)
+    assert x0.shape == (2,) and bool(((x0 >= 0) & (x0 <= 1)).all())
+    X, Y = loop.run(objective, 6)
+    assert X.shape == (6, 2) and Y.shape == (6, 1)
+    before = float(loop.model.mll())
+    utils.optimize_marginal_likelihood(loop.model, 1)
+    assert float(loop.model.mll()) >= before - 1e-8
+    assert bool((loop.model.weights >= 1e-10).all())
+    rng = np.random.default_rng(0)
+    random_best = min(objective(torch.from_numpy(rng.uniform(size=2))) for _ in range(6))
+    assert float(Y.min()) <= random_best + 5.0   # meta-learned prior should not be (much) worse than random search
+    ei = utils.ExpectedImprovement(loop.model, float(Y.min()))(torch.rand(5, 2, dtype=torch.float64))
+    assert bool((ei >= 0).all())
