@@ -78,6 +78,27 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
                            int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream);
 
 /*
+ * (1) Stand-alone kernel matrix K[t] = os_t k(X1_t / l_t, X2_t / l_t), (T, N1, N2).  X2 == NULL means
+ * X2 = X1 (N2 must equal N1; with add_noise != 0 the noise variance is added to the diagonal: the
+ * training matrix of scamlgp/model.py:36-70 + :25-33); x2_shared != 0 means X2 is one (N2, D) set
+ * used for every task (the cross-kernel K_* of gp.posterior(x), scamlgp/model.py:128).  The fused
+ * entry points never materialise K; this one exists for callers that want it.
+ */
+int scaml_kernel_matrix_f64(const double* X1, const double* X2, const double* theta, int T, int N1, int N2, int D,
+                            int kind, int x2_shared, int add_noise, double* K, void* stream);
+
+/*
+ * (2) Batched jittered Cholesky of GIVEN symmetric matrices A (T, N, N) (lower triangle read):
+ * the psd_safe_cholesky of linear_operator (reached from scamlgp/utils.py:171-177) for a whole
+ * stack, same in-kernel jitter escalation, status and outputs as scaml_gp_fit_fused_f64.  With a
+ * right-hand side y (T, N) it also returns alpha = A^-1 y, quad = y^T A^-1 y and logdet.  y, alpha,
+ * quad, logdet, jitter_used, Linv_diag may be NULL.  N <= scaml_fit_max_n().
+ */
+int scaml_potrf_batched_f64(const double* A, const double* y, const int32_t* n_points, const double* jitter_in,
+                            int T, int N, double* L, double* alpha, double* quad, double* logdet,
+                            int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream);
+
+/*
  * (5) Batched source-GP posteriors at M query points shared by all tasks.
  * Replaces the per-source loop `[gp.posterior(x) for gp in source_gps]` of
  *   scamlgp/model.py:128 (inside _compute_target_prior) and :281 (ScaMLGP.__init__ caches)

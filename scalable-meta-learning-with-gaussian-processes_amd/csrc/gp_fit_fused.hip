@@ -246,11 +246,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   const int N = p.N, D = p.D;
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
-  const double* Xg = p.X + (size_t)task * N * D;
-  const double* yg = p.y + (size_t)task * N;
-  const double* th = p.theta + (size_t)task * (D + 2);
-  const double os = th[D];
-  const double noise = th[D + 1];
+  const bool from_matrix = p.A_in != nullptr;   // POTRF mode: the matrix is given, nothing to evaluate
+  const double* Ag = from_matrix ? p.A_in + (size_t)task * N * N : nullptr;
+  const double* Xg = from_matrix ? nullptr : p.X + (size_t)task * N * D;
+  const double* yg = p.y ? p.y + (size_t)task * N : nullptr;
+  const double* th = from_matrix ? nullptr : p.theta + (size_t)task * (D + 2);
+  const double os = from_matrix ? 1.0 : th[D];
+  const double noise = from_matrix ? 0.0 : th[D + 1];
   const double jit_in = p.jitter_in ? p.jitter_in[task] : 0.0;
   double* Lg = (p.flags & SCAML_FIT_STORE_L) ? p.L + (size_t)task * N * N : nullptr;
   const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
@@ -267,7 +269,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   {
     const double diag_add = noise + jitter + jit_in;
     __syncthreads();  // previous attempt done with region A
-    if (tid < D) invl[tid] = 1.0 / th[tid];
+    if (!from_matrix && tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
     exp2_table_init(exptab, tid);
     if (!is_panel && lane == 0) {
@@ -289,8 +291,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
     for (int r = tid; r < NP; r += NTHREADS) {
       const bool in = r < n;
-      for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
-      ytil[r] = in ? yg[r] : 0.0;
+      if (!from_matrix)
+        for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+      ytil[r] = (in && yg) ? yg[r] : 0.0;
     }
     __syncthreads();
     STAMP(0);
@@ -304,22 +307,33 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (kj < NB) {                                                                             \
           const int col = 16 * kj + lc;                                                            \
           const int row0 = 16 * (kj + kr) + lq;                                                    \
-          double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                     \
-          _Pragma("unroll 2") for (int d = 0; d < D; ++d) {                                        \
-            const double* xr = xsT + d * NP;                                                       \
-            const double xc = xr[col];                                                             \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
-              double df = xr[row0 + 4 * g] - xc;                                                   \
-              d2[g] = __builtin_fma(df, df, d2[g]);                                                \
-            }                                                                                      \
-          }                                                                                        \
           double kt[4];                                                                            \
-          _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                          \
-            const int row = row0 + 4 * g;                                                          \
-            double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);                                      \
-            if (row == col) kv += diag_add;                                                        \
-            if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                                 \
-            kt[g] = kv;                                                                            \
+          if (from_matrix) {                                                                       \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+              const int row = row0 + 4 * g;                                                        \
+              double kv = 0.0;                                                                     \
+              if (row < n && col < n) kv = row >= col ? Ag[(size_t)row * N + col] : Ag[(size_t)col * N + row]; \
+              if (row == col) kv += diag_add;                                                      \
+              if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                               \
+              kt[g] = kv;                                                                          \
+            }                                                                                      \
+          } else {                                                                                 \
+            double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                   \
+            _Pragma("unroll 2") for (int d = 0; d < D; ++d) {                                      \
+              const double* xr = xsT + d * NP;                                                     \
+              const double xc = xr[col];                                                           \
+              _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
+                double df = xr[row0 + 4 * g] - xc;                                                 \
+                d2[g] = __builtin_fma(df, df, d2[g]);                                              \
+              }                                                                                    \
+            }                                                                                      \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
+              const int row = row0 + 4 * g;                                                        \
+              double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);                            \
+              if (row == col) kv += diag_add;                                                      \
+              if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                               \
+              kt[g] = kv;                                                                          \
+            }                                                                                      \
           }                                                                                        \
           TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                    \
           kr += WU;                                                                                \

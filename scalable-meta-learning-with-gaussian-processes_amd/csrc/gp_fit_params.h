@@ -10,6 +10,7 @@ struct FitParams {
   const double* theta;
   const int32_t* n_points;
   const double* jitter_in;
+  const double* A_in;       // (T, N, N) or NULL: factor this matrix (lower triangle read) instead of building K
   double* L;
   double* alpha;
   double* quad;

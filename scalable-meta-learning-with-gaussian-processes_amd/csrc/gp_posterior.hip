@@ -194,3 +194,30 @@ template __global__ void scaml::gp_posterior_kernel<0>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_kernel<1>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_cov_kernel<0>(scaml::PosteriorCovParams);
 template __global__ void scaml::gp_posterior_cov_kernel<1>(scaml::PosteriorCovParams);
+
+// (1) stand-alone kernel matrix: K[t][i][j] = os k(x1_i / l, x2_j / l) (+ noise on the diagonal of the
+// square case), one element per thread, rows of x2 coalesced across lanes.
+template <int KIND>
+__global__ void gp_kernel_matrix_kernel(scaml::KernelMatrixParams p) {
+  __shared__ double exptab[64];
+  scaml::exp2_table_init(exptab, threadIdx.x);
+  __syncthreads();
+  const int task = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= p.N2) return;
+  const int D = p.D;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double* x1 = p.X1 + ((size_t)task * p.N1 + i) * D;
+  const double* x2 = (p.X2 ? p.X2 + ((size_t)(p.x2_shared ? 0 : task) * p.N2 + j) * D : p.X1 + ((size_t)task * p.N1 + j) * D);
+  double d2 = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double df = (x1[d] - x2[d]) / th[d];
+    d2 = __builtin_fma(df, df, d2);
+  }
+  double kv = th[D] * scaml::kernel_from_sqdist<KIND>(d2, exptab);
+  if (!p.X2 && p.add_noise && i == j) kv += th[D + 1];
+  p.K[((size_t)task * p.N1 + i) * p.N2 + j] = kv;
+}
+template __global__ void gp_kernel_matrix_kernel<0>(scaml::KernelMatrixParams);
+template __global__ void gp_kernel_matrix_kernel<1>(scaml::KernelMatrixParams);

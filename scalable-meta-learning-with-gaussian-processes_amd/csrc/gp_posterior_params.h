@@ -30,6 +30,15 @@ struct PosteriorCovParams {
   int T, N, M, Ma, D;
 };
 
+struct KernelMatrixParams {
+  const double* X1;     // (T, N1, D)
+  const double* X2;     // (T, N2, D), (N2, D) when x2_shared, or NULL: X2 = X1 (square, symmetric)
+  const double* theta;  // (T, D+2)
+  double* K;            // (T, N1, N2)
+  int T, N1, N2, D;
+  int x2_shared, add_noise;
+};
+
 struct LinvParams {
   const double* L;          // (T, N, N)
   const double* Linv_diag;  // (T, ceil(N/16), 16, 16)

@@ -43,6 +43,7 @@ struct Module {
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t wsum = nullptr;
   hipFunction_t linv = nullptr;
+  hipFunction_t kmat[2] = {nullptr, nullptr};
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
@@ -75,6 +76,8 @@ struct Module {
       char name[128];
       snprintf(name, sizeof(name), "_ZN5scaml18gp_mll_grad_kernelILi%dEEEvNS_13MllGradParamsE", kind);
       if ((e = hipModuleGetFunction(&mllgrad[kind], mod, name)) != hipSuccess) return e;
+      snprintf(name, sizeof(name), "_Z23gp_kernel_matrix_kernelILi%dEEvN5scaml18KernelMatrixParamsE", kind);
+      if ((e = hipModuleGetFunction(&kmat[kind], mod, name)) != hipSuccess) return e;
     }
     loaded = true;
     return hipSuccess;
@@ -109,6 +112,28 @@ int scaml_fit_max_d(int N) {
   return d > 1024 ? 1024 : d;
 }
 
+static int fit_common(scaml::FitParams p, int kind, void* stream) {
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) {
+    set_error("loading the gfx950 code object", e);
+    return SCAML_E_LAUNCH;
+  }
+  const int N = p.N;
+  const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
+  const size_t lds = fit_lds_bytes(v.nb, v.wu, p.D);
+  if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(v.fn[kind], (unsigned)p.T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
+                            (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) {
+    set_error("hipModuleLaunchKernel(gp_fit_fused)", e);
+    return SCAML_E_LAUNCH;
+  }
+  return SCAML_OK;
+}
+
 int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta,
                            const int32_t* n_points, const double* jitter_in,
                            int T, int N, int D, int kind,
@@ -121,25 +146,22 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
   if (N > scaml_fit_max_n()) return SCAML_E_TOOLARGE;
   if (D > scaml_fit_max_d(N)) return SCAML_E_TOOLARGE;
   if (T == 0) return SCAML_OK;
-  Module& m = module();
-  hipError_t e = m.load();
-  if (e != hipSuccess) {
-    set_error("loading the gfx950 code object", e);
-    return SCAML_E_LAUNCH;
-  }
-  const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
-  const size_t lds = fit_lds_bytes(v.nb, v.wu, D);
-  if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
-  scaml::FitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag, T, N, D, flags};
-  size_t psize = sizeof(p);
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(v.fn[kind], (unsigned)T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
-                            (hipStream_t)stream, nullptr, config);
-  if (e != hipSuccess) {
-    set_error("hipModuleLaunchKernel(gp_fit_fused)", e);
-    return SCAML_E_LAUNCH;
-  }
-  return SCAML_OK;
+  scaml::FitParams p{X, y, theta, n_points, jitter_in, nullptr, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag, T, N, D, flags};
+  return fit_common(p, kind, stream);
+}
+
+// ---- (2) batched jittered Cholesky of given matrices ------------------------------------------------
+int scaml_potrf_batched_f64(const double* A, const double* y, const int32_t* n_points, const double* jitter_in,
+                            int T, int N, double* L, double* alpha, double* quad, double* logdet,
+                            int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream) {
+  if (T < 0 || N < 1) return SCAML_E_BADARG;
+  if (!A || !info) return SCAML_E_BADARG;
+  if ((flags & SCAML_FIT_STORE_L) && !L) return SCAML_E_BADARG;
+  if (alpha && !y) return SCAML_E_BADARG;
+  if (N > scaml_fit_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  scaml::FitParams p{nullptr, y, nullptr, n_points, jitter_in, A, L, alpha, quad, logdet, nullptr, info, jitter_used, Linv_diag, T, N, 1, flags};
+  return fit_common(p, SCAML_KIND_RBF, stream);
 }
 
 // ---- (5) batched source posteriors ------------------------------------------------------------
@@ -211,6 +233,26 @@ int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t
   void* args[] = {(void*)&in, (void*)&w, (void*)&active, (void*)&T, (void*)&len, (void*)&power, (void*)&out};
   e = hipModuleLaunchKernel(m.wsum, (unsigned)((len + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(weighted_task_sum)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+// ---- (1) stand-alone kernel matrix ---------------------------------------------------------------
+int scaml_kernel_matrix_f64(const double* X1, const double* X2, const double* theta, int T, int N1, int N2, int D,
+                            int kind, int x2_shared, int add_noise, double* K, void* stream) {
+  if (T < 0 || N1 < 1 || N2 < 1 || D < 1) return SCAML_E_BADARG;
+  if (!X1 || !theta || !K) return SCAML_E_BADARG;
+  if (!X2 && N1 != N2) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (T == 0) return SCAML_OK;
+  if (N1 > 65535 || T > 65535) return SCAML_E_TOOLARGE;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  scaml::KernelMatrixParams p{X1, X2, theta, K, T, N1, N2, D, x2_shared, add_noise};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m.kmat[kind], (unsigned)((N2 + 127) / 128), (unsigned)N1, (unsigned)T, 128, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_kernel_matrix)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
 

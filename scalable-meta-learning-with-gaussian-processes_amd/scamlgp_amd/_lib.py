@@ -60,6 +60,10 @@ def _load() -> ctypes.CDLL:
         _dp, _dp, _dp, _dp, _dp,  # L, alpha, quad, logdet, mll
         _dp, _dp, _dp, c_uint, c_void_p,  # info, jitter_used, Linv_diag, flags, stream
     ]
+    lib.scaml_kernel_matrix_f64.restype = c_int
+    lib.scaml_kernel_matrix_f64.argtypes = [_dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]
+    lib.scaml_potrf_batched_f64.restype = c_int
+    lib.scaml_potrf_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, c_uint, c_void_p]
     lib.scaml_posterior_max_n.restype = c_int
     lib.scaml_posterior_max_n.argtypes = []
     lib.scaml_posterior_batched_f64.restype = c_int
@@ -88,6 +92,8 @@ EXPORTED_SYMBOLS = (
     "scaml_fit_max_n",
     "scaml_fit_max_d",
     "scaml_gp_fit_fused_f64",
+    "scaml_kernel_matrix_f64",
+    "scaml_potrf_batched_f64",
     "scaml_posterior_max_n",
     "scaml_posterior_batched_f64",
     "scaml_posterior_cov_f64",

@@ -107,6 +107,59 @@ def gp_fit_fused(
     return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used, Linv_diag=linv)
 
 
+def kernel_matrix(X1: torch.Tensor, theta: torch.Tensor, kind: int, X2: Optional[torch.Tensor] = None,
+                  add_noise: bool = False) -> torch.Tensor:
+    """K (T, N1, N2) = os k(X1 / l, X2 / l).  X2 None: square training matrix (optionally + noise I);
+    X2 (N2, D): one query set shared by all tasks; X2 (T, N2, D): per-task.  scaml_kernel_matrix_f64."""
+    T, N1, D = X1.shape
+    X1 = _check(X1, "X1")
+    theta = _check(theta, "theta", (T, D + 2))
+    shared = 0
+    N2 = N1
+    if X2 is not None:
+        shared = 1 if X2.dim() == 2 else 0
+        N2 = X2.shape[-2]
+        X2 = _check(X2, "X2", (N2, D) if shared else (T, N2, D))
+    K = torch.empty((T, N1, N2), dtype=torch.float64, device=X1.device)
+    with torch.cuda.device(X1.device):
+        rc = _lib.lib.scaml_kernel_matrix_f64(_ptr(X1), _ptr(X2), _ptr(theta), T, N1, N2, D, int(kind), shared,
+                                              1 if add_noise else 0, _ptr(K), _stream_handle())
+    _lib.check_rc(rc, "scaml_kernel_matrix_f64")
+    return K
+
+
+def potrf_batched(A: torch.Tensor, y: Optional[torch.Tensor] = None, n_points: Optional[torch.Tensor] = None,
+                  jitter: Optional[torch.Tensor] = None, zero_upper: bool = True, retry: bool = True,
+                  want_linv: bool = False) -> Dict[str, torch.Tensor]:
+    """Jittered Cholesky of a stack of given SPD matrices A (T, N, N) (+ optional solve with y (T, N)).
+    Returns dict(L, alpha, quad, logdet, info, jitter, Linv_diag).  scaml_potrf_batched_f64."""
+    if A.dim() != 3 or A.shape[1] != A.shape[2]:
+        raise ValueError("A must be (T, N, N)")
+    T, N, _ = A.shape
+    A = _check(A, "A")
+    if y is not None:
+        y = _check(y, "y", (T, N))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    if jitter is not None:
+        jitter = _check(jitter, "jitter", (T,))
+    dev = A.device
+    with torch.cuda.device(dev):
+        L = torch.zeros((T, N, N), dtype=torch.float64, device=dev) if n_points is not None else torch.empty((T, N, N), dtype=torch.float64, device=dev)
+        alpha = torch.zeros((T, N), dtype=torch.float64, device=dev) if y is not None else None
+        quad = torch.empty((T,), dtype=torch.float64, device=dev) if y is not None else None
+        logdet = torch.empty((T,), dtype=torch.float64, device=dev)
+        info = torch.empty((T,), dtype=torch.int32, device=dev)
+        jit_used = torch.empty((T,), dtype=torch.float64, device=dev)
+        linv = torch.empty((T, (N + 15) // 16, 16, 16), dtype=torch.float64, device=dev) if want_linv else None
+        flags = _lib.FIT_STORE_L | (_lib.FIT_ZERO_UPPER if zero_upper else 0) | (0 if retry else _lib.FIT_NO_RETRY)
+        rc = _lib.lib.scaml_potrf_batched_f64(_ptr(A), _ptr(y), _ptr(n_points), _ptr(jitter), T, N, _ptr(L), _ptr(alpha),
+                                              _ptr(quad), _ptr(logdet), _ptr(info), _ptr(jit_used), _ptr(linv), flags,
+                                              _stream_handle())
+    _lib.check_rc(rc, "scaml_potrf_batched_f64")
+    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, info=info, jitter=jit_used, Linv_diag=linv)
+
+
 def source_posteriors(
     Xq: torch.Tensor,
     X: torch.Tensor,
