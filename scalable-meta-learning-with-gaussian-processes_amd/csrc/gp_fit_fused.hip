@@ -54,6 +54,13 @@ namespace scaml {
 // (lane -> row (lane >> 4) + 4g, column lane & 15) and the per-row reads are all bank-conflict free.
 constexpr int PP = 17;
 
+// a wave-uniform 64-bit value, made visibly so for the compiler (SGPR pair operand of asm)
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ int opaque_s(int v) {
   asm volatile("" : "+s"(v));  // keeps per-slot address arithmetic from being hoisted out of the panel loop
   return v;
@@ -370,6 +377,47 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     fail = flagp[0];
 
     if (!fail) {
+      // Finished tiles of column k: registers -> HBM as 128-byte row segments; the mirrored upper tile is
+      // written as zeros by the same lanes (no separate zero-fill pass over L).
+      auto store_column = [&](int k) {
+        if (Lg) {
+          const int sa = slo(k), sb = slo(k + 1), offk = off(k);
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + (s * WU + wave - offk);
+            double e[4];
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
+            {
+              double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
+              double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
+              if (16 * ti + 16 <= n && ti != k) {                   // interior tile: no per-lane bounds
+                // scalar row base + one 32-bit lane offset per store (saddr form): 1 SALU add + 1 store per
+                // group of four 128-byte segments instead of 64-bit VALU address arithmetic per store
+                const unsigned voff = (unsigned)lane_idx * 8u;
+                const double zero = 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const unsigned long long rowb = uniform_u64((unsigned long long)(tb + (size_t)g * 4 * N));
+                  asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(e[g]), "s"(rowb) : "memory");
+                  if (zero_upper) {
+                    const unsigned long long mrow = uniform_u64((unsigned long long)(mb + (size_t)g * 4 * N));
+                    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(zero), "s"(mrow) : "memory");
+                  }
+                }
+              } else {
+                const int col = 16 * k + lc, mc = 16 * ti + lc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;
+                  if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                  if (zero_upper && ti != k && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+                }
+              }
+            }
+          }
+        }
+      };
       for (int k = 0; k < NB; ++k) {
         double* buf = PT + (k & 1) * PANEL;         // panel k: diagonal block final, rows below raw
         double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1
@@ -393,8 +441,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_BODY
           }
           MFMA_DRAIN();
-          // final tiles: back to the panel for everyone's operand reads, out to HBM from registers
-          // (128-byte row segments; the mirrored upper tile is written as zeros by the same lanes)
+          // final tiles: back to the panel for everyone's operand reads (their way to HBM waits until
+          // after barrier X, off the critical path)
           for (int s = sa; s < sb; ++s) {
             const int ti = k + (s * WU + wave - offk);
             double e[4];
@@ -409,31 +457,15 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
               for (int g = 0; g < 4; ++g)
                 if (lc == lq + 4 * g) dl[16 * k + lc] = e[g];
             }
-            if (Lg) {
-              double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
-              double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
-              if (16 * ti + 16 <= n && ti != k) {                   // interior tile: no per-lane bounds
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                  if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-                }
-              } else {
-                const int col = 16 * k + lc, mc = 16 * ti + lc;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;
-                  if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                  if (zero_upper && ti != k && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-                }
-              }
-            }
           }
         }
         STAMP(3);
         __syncthreads();  // Z: panel k final in LDS
         STAMP(4);
-        if (k + 1 == NB) break;
+        if (k + 1 == NB) {
+          if (!is_panel) store_column(k);
+          break;
+        }
         if (is_panel) {
           // running right-hand side: y_r -= L[r, panel k] . v_k for every row below the block
           double vk[16];
@@ -481,6 +513,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           __builtin_amdgcn_s_setprio(0);
           if (bad && lane == 0) flagp[0] = bad;
         } else {
+          // column k out to HBM — deliberately here, after barrier X: nobody waits for these stores
+          store_column(k);
           // U2: the bulk of the trailing update, overlapped with the panel wave: every slot from
           // slo(k+2) on, entered through one switch and then falling through slot after slot
           const int s0 = slo(k + 2);
