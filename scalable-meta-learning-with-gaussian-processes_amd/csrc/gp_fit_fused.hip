@@ -54,13 +54,6 @@ namespace scaml {
 // (lane -> row (lane >> 4) + 4g, column lane & 15) and the per-row reads are all bank-conflict free.
 constexpr int PP = 17;
 
-// a wave-uniform 64-bit value, made visibly so for the compiler (SGPR pair operand of asm)
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-
 __device__ __forceinline__ int opaque_s(int v) {
   asm volatile("" : "+s"(v));  // keeps per-slot address arithmetic from being hoisted out of the panel loop
   return v;
@@ -392,18 +385,10 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
               double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
               double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
               if (16 * ti + 16 <= n && ti != k) {                   // interior tile: no per-lane bounds
-                // scalar row base + one 32-bit lane offset per store (saddr form): 1 SALU add + 1 store per
-                // group of four 128-byte segments instead of 64-bit VALU address arithmetic per store
-                const unsigned voff = (unsigned)lane_idx * 8u;
-                const double zero = 0.0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                  const unsigned long long rowb = uniform_u64((unsigned long long)(tb + (size_t)g * 4 * N));
-                  asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(e[g]), "s"(rowb) : "memory");
-                  if (zero_upper) {
-                    const unsigned long long mrow = uniform_u64((unsigned long long)(mb + (size_t)g * 4 * N));
-                    asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(zero), "s"(mrow) : "memory");
-                  }
+                  tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                  if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
                 }
               } else {
                 const int col = 16 * k + lc, mc = 16 * ti + lc;
@@ -441,8 +426,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_BODY
           }
           MFMA_DRAIN();
-          // final tiles: back to the panel for everyone's operand reads (their way to HBM waits until
-          // after barrier X, off the critical path)
+          // final tiles: back to the panel for everyone's operand reads
           for (int s = sa; s < sb; ++s) {
             const int ti = k + (s * WU + wave - offk);
             double e[4];
@@ -459,13 +443,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             }
           }
         }
+        // (issuing these stores after barrier X instead — off the critical path — measured 4 % slower:
+        //  they then compete with the bulk update for issue slots; interleaved A/B, tools/dev_ab.py)
+        if (!is_panel) store_column(k);
         STAMP(3);
         __syncthreads();  // Z: panel k final in LDS
         STAMP(4);
-        if (k + 1 == NB) {
-          if (!is_panel) store_column(k);
-          break;
-        }
+        if (k + 1 == NB) break;
         if (is_panel) {
           // running right-hand side: y_r -= L[r, panel k] . v_k for every row below the block
           double vk[16];
@@ -513,8 +497,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           __builtin_amdgcn_s_setprio(0);
           if (bad && lane == 0) flagp[0] = bad;
         } else {
-          // column k out to HBM — deliberately here, after barrier X: nobody waits for these stores
-          store_column(k);
           // U2: the bulk of the trailing update, overlapped with the panel wave: every slot from
           // slo(k+2) on, entered through one switch and then falling through slot after slot
           const int s0 = slo(k + 2);
