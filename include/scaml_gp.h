@@ -108,12 +108,16 @@ int scaml_potrf_batched_f64(const double* A, const double* y, const int32_t* n_p
  *   Xq (M, D); L, alpha, Linv_diag as produced by scaml_gp_fit_fused_f64 with the same X, theta.
  *   mu (T, M), var (T, M) = diagonal of Sigma, V (T, N, M) = L^-1 K_*^T (un-scaled): each may be
  *   NULL.  N <= scaml_posterior_max_n().
+ *   flags: SCAML_POST_XQ_PER_TASK — Xq is (T, M, D), one query set per task;
+ *          SCAML_POST_MEAN_ONLY   — only mu = m + s K_* alpha (no solve; L, Linv_diag, var, V unused/NULL).
  */
+#define SCAML_POST_XQ_PER_TASK 1u
+#define SCAML_POST_MEAN_ONLY 2u
 int scaml_posterior_max_n(void);
 int scaml_posterior_batched_f64(const double* Xq, const double* X, const double* theta, const double* L,
                                 const double* Linv_diag, const double* alpha, const double* y_mean,
                                 const double* y_std, const int32_t* n_points, int T, int N, int M, int D, int kind,
-                                double* mu, double* var, double* V, void* stream);
+                                double* mu, double* var, double* V, unsigned flags, void* stream);
 
 /*
  * (5b) Covariance block of the same posteriors between the first Ma query points and all M:
@@ -122,7 +126,15 @@ int scaml_posterior_batched_f64(const double* Xq, const double* X, const double*
  * scamlgp/model.py:287-289 / :131 without recomputing the train block per query.
  */
 int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double* V, const double* y_std,
-                            int T, int N, int M, int Ma, int D, int kind, double* cov, void* stream);
+                            int T, int N, int M, int Ma, int D, int kind, double* cov, unsigned flags, void* stream);
+
+/*
+ * Batched Cholesky solve Xout = (L L^T)^-1 B for R right-hand sides per task, B and Xout (T, N, R), with
+ * the L and Linv_diag of a fused fit / POTRF (gpytorch's cholesky_solve behind prediction caches and
+ * inv_quad for new right-hand sides).  Forward and backward substitution as blocked MFMA products.
+ */
+int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                                int T, int N, int R, double* Xout, void* stream);
 
 /*
  * (6) Weighted sum over the task axis: out[e] = sum_t c_t in[t][e], c_t = w_t (power 1) or w_t^2

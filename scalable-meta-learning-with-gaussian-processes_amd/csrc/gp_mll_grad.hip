@@ -64,6 +64,80 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
   }
 }
 
+// X = (L L^T)^-1 B for R right-hand-side columns per task: one wave per (task, strip of 16 columns).
+// Forward: Y_kb = W_kb (B_kb - sum_{j<kb} L_kb,j Y_j); backward: X_kb = W_kb^T (Y_kb - sum_{j>kb} L_j,kb^T X_j).
+// Every block product is 4 MFMAs; solved blocks live in the wave's LDS strip in B-operand position.
+__global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
+  extern __shared__ double lds[];
+  const int N = p.N, R = p.R, NB = (N + 15) / 16, NP = NB * 16;
+  const int task = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  int n = p.n_points ? p.n_points[task] : N;
+  n = n < 0 ? 0 : (n > N ? N : n);
+  double* Vs = lds + (size_t)wave * NP * 16;
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * NB * 256;
+  const double* Bg = p.B + (size_t)task * N * R;
+  double* Og = p.Xout + (size_t)task * N * R;
+  const int strip = blockIdx.x * nwaves + wave;
+  if (16 * strip >= R) return;
+  const int qc = 16 * strip + lc;
+  // forward substitution
+  for (int kb = 0; kb < NB; ++kb) {
+    d4_t acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + lq + 4 * g;
+      acc[g] = (row < n && qc < R) ? Bg[(size_t)row * R + qc] : 0.0;
+    }
+    const int arow = 16 * kb + lc;
+    const bool arow_ok = arow < n;
+    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
+    for (int j = 0; j < kb; ++j) {
+      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int col = 16 * j + 4 * m + lq;
+        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
+      }
+    }
+    d4_t v = {0.0, 0.0, 0.0, 0.0};
+    const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Vs[(16 * kb + lq + 4 * g) * 16 + lc] = v[g];
+  }
+  // backward substitution (in place in the strip: block kb is overwritten once all j > kb are final)
+  for (int kb = NB - 1; kb >= 0; --kb) {
+    d4_t acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = Vs[(16 * kb + lq + 4 * g) * 16 + lc];
+    for (int j = kb + 1; j < NB; ++j) {
+      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        // A[i = lc][k = lq] = L[16 j + 4 m + lq][16 kb + lc]  (the transposed tile)
+        const int r = 16 * j + 4 * m + lq, c = 16 * kb + lc;
+        const double a = (r < n && c < n) ? Lg[(size_t)r * N + c] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
+      }
+    }
+    d4_t v = {0.0, 0.0, 0.0, 0.0};
+    const double* wcol = Wg + (size_t)kb * 256 + lq * 16 + lc;   // A[i = lc][k = lq] = W[4 m + lq][lc]
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wcol[4 * m * 16], acc[m], v, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + lq + 4 * g;
+      Vs[row * 16 + lc] = v[g];
+      if (row < N && qc < R) Og[(size_t)row * R + qc] = row < n ? v[g] : 0.0;
+    }
+  }
+}
+
 // kernel value k (without outputscale) and h with dk/dl_d = h * delta_d^2 / l_d^3
 template <int KIND>
 __device__ __forceinline__ void kernel_and_dfactor(double d2, const double* exptab, double& k, double& h) {

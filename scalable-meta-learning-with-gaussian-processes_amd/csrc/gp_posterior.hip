@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
   const int c0 = strip * 16;
   const int qc = c0 + lc;   // this lane's query point
   if (lq == 0) {
-    for (int d = 0; d < D; ++d) xqs[d * 16 + lc] = qc < M ? p.Xq[(size_t)qc * D + d] * invl[d] : 0.0;
+    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
+    for (int d = 0; d < D; ++d) xqs[d * 16 + lc] = qc < M ? Xqg[(size_t)qc * D + d] * invl[d] : 0.0;
   }
   __syncthreads();
   if (c0 >= M) return;   // (no barrier below: waves are independent from here)
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
         mean_part = __builtin_fma(kv, alpha_s[row], mean_part);
       }
     }
+    if (p.mean_only) continue;
     // acc -= L[kb, j] V_j for the row blocks already solved
     const int arow = 16 * kb + lc;
     const bool arow_ok = arow < n;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(256) void gp_posterior_cov_kernel(PosteriorCovParam
   const double os = th[D];
   const double ys = p.y_std ? p.y_std[task] : 1.0;
   const double* Vg = p.V + (size_t)task * N * M;
+  const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
   // -V_a^T V_c: A operand lane (i = lc -> point a, k = lq -> training row), B operand lane (k = lq, j = lc -> point c)
   const int pa = 16 * ta + lc, pc = 16 * tc + lc;
   d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void gp_posterior_cov_kernel(PosteriorCovParam
     if (a < Ma && pc < M) {
       double d2 = 0.0;
       for (int d = 0; d < D; ++d) {
-        const double df = (p.Xq[(size_t)a * D + d] - p.Xq[(size_t)pc * D + d]) / th[d];
+        const double df = (Xqg[(size_t)a * D + d] - Xqg[(size_t)pc * D + d]) / th[d];
         d2 = __builtin_fma(df, df, d2);
       }
       const double kv = os * kernel_from_sqdist<KIND>(d2, exptab);

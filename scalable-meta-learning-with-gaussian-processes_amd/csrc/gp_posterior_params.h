@@ -19,6 +19,8 @@ struct PosteriorParams {
   double* V;                // (T, N, M) or NULL
   int T, N, M, D;
   int x_in_lds;
+  int xq_per_task;  // Xq is (T, M, D) instead of (M, D)
+  int mean_only;    // skip the triangular solve: only mu = m + s K_* alpha is produced
 };
 
 struct PosteriorCovParams {
@@ -28,6 +30,16 @@ struct PosteriorCovParams {
   const double* y_std;  // (T) or NULL
   double* cov;          // (T, Ma, M)
   int T, N, M, Ma, D;
+  int xq_per_task;
+};
+
+struct ChoSolveParams {
+  const double* L;          // (T, N, N)
+  const double* Linv_diag;  // (T, ceil(N/16), 16, 16)
+  const double* B;          // (T, N, R) right-hand sides
+  const int32_t* n_points;  // (T) or NULL
+  double* Xout;             // (T, N, R): (L L^T)^-1 B
+  int T, N, R;
 };
 
 struct KernelMatrixParams {

@@ -44,6 +44,7 @@ struct Module {
   hipFunction_t wsum = nullptr;
   hipFunction_t linv = nullptr;
   hipFunction_t kmat[2] = {nullptr, nullptr};
+  hipFunction_t chosolve = nullptr;
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
@@ -72,6 +73,8 @@ struct Module {
     if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&linv, mod, "_ZN5scaml14gp_linv_kernelENS_10LinvParamsE")) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)linv, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipModuleGetFunction(&chosolve, mod, "_ZN5scaml19gp_cho_solve_kernelENS_14ChoSolveParamsE")) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)chosolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     for (int kind = 0; kind < 2; ++kind) {
       char name[128];
       snprintf(name, sizeof(name), "_ZN5scaml18gp_mll_grad_kernelILi%dEEEvNS_13MllGradParamsE", kind);
@@ -175,9 +178,10 @@ int scaml_posterior_max_n(void) { return 512; }
 int scaml_posterior_batched_f64(const double* Xq, const double* X, const double* theta, const double* L,
                                 const double* Linv_diag, const double* alpha, const double* y_mean,
                                 const double* y_std, const int32_t* n_points, int T, int N, int M, int D, int kind,
-                                double* mu, double* var, double* V, void* stream) {
+                                double* mu, double* var, double* V, unsigned flags, void* stream) {
   if (T < 0 || N < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
-  if (!Xq || !X || !theta || !L || !Linv_diag || !alpha) return SCAML_E_BADARG;
+  if (!Xq || !X || !theta || !alpha) return SCAML_E_BADARG;
+  if (!(flags & SCAML_POST_MEAN_ONLY) && (!L || !Linv_diag)) return SCAML_E_BADARG;
   if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
   if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
   if (T == 0 || M == 0) return SCAML_OK;
@@ -192,7 +196,9 @@ int scaml_posterior_batched_f64(const double* Xq, const double* X, const double*
   Module& m = module();
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
-  scaml::PosteriorParams p{Xq, X, theta, L, Linv_diag, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0};
+  const int per_task = (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, mean_only = (flags & SCAML_POST_MEAN_ONLY) ? 1 : 0;
+  if (mean_only && (var || V)) return SCAML_E_BADARG;
+  scaml::PosteriorParams p{Xq, X, theta, L, Linv_diag, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0, per_task, mean_only};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const int strips = (M + 15) / 16;
@@ -203,7 +209,7 @@ int scaml_posterior_batched_f64(const double* Xq, const double* X, const double*
 }
 
 int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double* V, const double* y_std,
-                            int T, int N, int M, int Ma, int D, int kind, double* cov, void* stream) {
+                            int T, int N, int M, int Ma, int D, int kind, double* cov, unsigned flags, void* stream) {
   if (T < 0 || N < 1 || M < 0 || Ma < 0 || Ma > M || D < 1) return SCAML_E_BADARG;
   if (!Xq || !theta || !V || !cov) return SCAML_E_BADARG;
   if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
@@ -211,7 +217,7 @@ int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double*
   Module& m = module();
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
-  scaml::PosteriorCovParams p{Xq, theta, V, y_std, cov, T, N, M, Ma, D};
+  scaml::PosteriorCovParams p{Xq, theta, V, y_std, cov, T, N, M, Ma, D, (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const int tiles_c = (M + 15) / 16, tiles_a = (Ma + 15) / 16;
@@ -253,6 +259,28 @@ int scaml_kernel_matrix_f64(const double* X1, const double* X2, const double* th
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m.kmat[kind], (unsigned)((N2 + 127) / 128), (unsigned)N1, (unsigned)T, 128, 1, 1, 0, (hipStream_t)stream, nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_kernel_matrix)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+// ---- batched Cholesky solve ----------------------------------------------------------------------
+int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                                int T, int N, int R, double* Xout, void* stream) {
+  if (T < 0 || N < 1 || R < 0) return SCAML_E_BADARG;
+  if (!L || !Linv_diag || !B || !Xout) return SCAML_E_BADARG;
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0 || R == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  const int nb = (N + 15) / 16, np = nb * 16, strips = (R + 15) / 16;
+  int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
+  if (waves > strips) waves = strips;
+  scaml::ChoSolveParams p{L, Linv_diag, B, n_points, Xout, T, N, R};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m.chosolve, (unsigned)((strips + waves - 1) / waves), (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
+                            (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_cho_solve)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
 

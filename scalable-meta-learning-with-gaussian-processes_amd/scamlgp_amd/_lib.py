@@ -26,6 +26,8 @@ KIND_MATERN52 = 1
 FIT_STORE_L = 1
 FIT_ZERO_UPPER = 2
 FIT_NO_RETRY = 4
+POST_XQ_PER_TASK = 1
+POST_MEAN_ONLY = 2
 
 E_BADARG = -1
 E_TOOLARGE = -2
@@ -70,10 +72,12 @@ def _load() -> ctypes.CDLL:
     lib.scaml_posterior_batched_f64.argtypes = [
         _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,  # Xq, X, theta, L, Linv_diag, alpha, y_mean, y_std, n_points
         c_int, c_int, c_int, c_int, c_int,  # T, N, M, D, kind
-        _dp, _dp, _dp, c_void_p,  # mu, var, V, stream
+        _dp, _dp, _dp, ctypes.c_uint, c_void_p,  # mu, var, V, flags, stream
     ]
     lib.scaml_posterior_cov_f64.restype = c_int
-    lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, c_void_p]
+    lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.c_uint, c_void_p]
+    lib.scaml_cho_solve_batched_f64.restype = c_int
+    lib.scaml_cho_solve_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, c_void_p]
     lib.scaml_weighted_task_sum_f64.restype = c_int
     lib.scaml_weighted_task_sum_f64.argtypes = [_dp, _dp, _dp, c_int, ctypes.c_longlong, c_int, _dp, c_void_p]
     lib.scaml_mll_backward_workspace_doubles.restype = ctypes.c_longlong
@@ -97,6 +101,7 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_max_n",
     "scaml_posterior_batched_f64",
     "scaml_posterior_cov_f64",
+    "scaml_cho_solve_batched_f64",
     "scaml_weighted_task_sum_f64",
     "scaml_mll_backward_workspace_doubles",
     "scaml_mll_backward_f64",

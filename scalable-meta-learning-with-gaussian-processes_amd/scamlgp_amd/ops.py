@@ -70,6 +70,10 @@ def gp_fit_fused(
         n_points = _check(n_points, "n_points", (T,), torch.int32)
     if jitter is not None:
         jitter = _check(jitter, "jitter", (T,))
+    if N > _lib.lib.scaml_fit_max_n():
+        if out is not None:
+            raise ValueError("out= is not supported beyond scaml_fit_max_n()")
+        return _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry)
     dev = X.device
     with torch.cuda.device(dev):
         if out is not None:
@@ -105,6 +109,89 @@ def gp_fit_fused(
         )
     _lib.check_rc(rc, "scaml_gp_fit_fused_f64")
     return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used, Linv_diag=linv)
+
+
+_JITTER_LADDER = (1e-8, 1e-7, 1e-6)  # psd_safe_cholesky's escalation
+
+
+def _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry) -> Dict[str, torch.Tensor]:
+    """Fused fit for scaml_fit_max_n() < N <= 2 * scaml_fit_max_n() (the N = 512 source tasks of
+    BASELINE config 5) as a 2 x 2 block factorisation composed from the library's own launches:
+
+        [K11 K12]   [L11      ] [L11^T  V  ]      L11 = fused fit of block 1 (register-resident kernel)
+        [K21 K22] = [V^T   L22] [      L22^T]     V   = L11^-1 K12          (scaml_posterior_batched_f64)
+                                                  S   = K22 - V^T V          (scaml_posterior_cov_f64)
+                                                  L22 = chol(S + noise I)    (scaml_potrf_batched_f64)
+
+    The posterior of block 1 at the points of block 2 is exactly the conditional the Schur complement
+    needs: alpha_2 = S^-1 (y_2 - K21 K11^-1 y_1) falls out of the POTRF's solve, and
+    alpha_1 = alpha_1' - K11^-1 K12 alpha_2 (mean-only cross product + scaml_cho_solve_batched_f64).
+    quad and logdet add over the blocks.  The jitter ladder is driven from the host here (one
+    status read per attempt; every attempt is single-shot in the kernels) so that, like
+    psd_safe_cholesky, one jitter value applies to the whole matrix of a failing task only.
+    Torch is used for slicing/concatenation only.
+    """
+    T, N, D = X.shape
+    N1 = _lib.lib.scaml_fit_max_n()
+    if N > 2 * N1:
+        raise ValueError(f"N = {N} exceeds the supported {2 * N1} points per task")
+    N2 = N - N1
+    dev = X.device
+    X1, X2 = X[:, :N1].contiguous(), X[:, N1:].contiguous()
+    y1, y2 = y[:, :N1].contiguous(), y[:, N1:].contiguous()
+    n1 = n2 = None
+    if n_points is not None:
+        n1 = n_points.clamp(max=N1).to(torch.int32)
+        n2 = (n_points - N1).clamp(min=0).to(torch.int32)
+    noise = theta[:, D + 1].contiguous()
+    jit = torch.zeros((T,), dtype=torch.float64, device=dev)
+    base = jitter if jitter is not None else torch.zeros((T,), dtype=torch.float64, device=dev)
+    for step in range(len(_JITTER_LADDER) + 1):
+        f1 = gp_fit_fused(X1, y1, theta, kind, n_points=n1, jitter=base + jit, retry=False, want_linv=True)
+        p12 = source_posteriors(X2, X1, theta, kind, f1["L"], f1["Linv_diag"], f1["alpha"], n_points=n1,
+                                want_var=False, cov_first=N2, keep_V=True)
+        f2 = potrf_batched(p12["cov"], y2 - p12["mean"], n_points=n2, jitter=noise + base + jit, retry=False,
+                           want_linv=True)
+        info = torch.where(f1["info"] > 0, f1["info"], torch.where(f2["info"] > 0, f2["info"] + N1, f2["info"]))
+        failed = info > 0
+        if not retry or step == len(_JITTER_LADDER) or not bool(failed.any()):
+            break
+        jit = torch.where(failed, torch.full_like(jit, _JITTER_LADDER[step]), jit)
+    k12a2 = source_posteriors(X1, X2, theta, kind, None, None, f2["alpha"], n_points=n2, mean_only=True)["mean"]
+    u = cho_solve(f1["L"], f1["Linv_diag"], k12a2.unsqueeze(-1), n_points=n1).squeeze(-1)
+    alpha = torch.cat([f1["alpha"] - u, f2["alpha"]], 1)
+    quad = f1["quad"] + f2["quad"]
+    logdet = f1["logdet"] + f2["logdet"]
+    n = n_points.to(torch.float64) if n_points is not None else torch.full((T,), float(N), dtype=torch.float64, device=dev)
+    mll = -(quad + logdet + n * 1.8378770664093453) / (2.0 * n.clamp_min(1.0))
+    L = None
+    if store_L:
+        L = torch.zeros((T, N, N), dtype=torch.float64, device=dev)
+        L[:, :N1, :N1] = f1["L"]
+        Vt = p12["V"].transpose(1, 2)
+        if n2 is not None:
+            Vt = Vt * (torch.arange(N2, device=dev)[None, :, None] < n2[:, None, None])
+        L[:, N1:, :N1] = Vt
+        L[:, N1:, N1:] = f2["L"]
+    linv = torch.cat([f1["Linv_diag"], f2["Linv_diag"]], 1)
+    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info.to(torch.int32), jitter=jit, Linv_diag=linv)
+
+
+def cho_solve(L: torch.Tensor, Linv_diag: torch.Tensor, B: torch.Tensor, n_points: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(L L^T)^-1 B for B (T, N, R) with the factors of a fused fit.  scaml_cho_solve_batched_f64."""
+    T, N, _ = L.shape
+    R = B.shape[-1]
+    L = _check(L, "L", (T, N, N))
+    Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
+    B = _check(B, "B", (T, N, R))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    out = torch.empty_like(B)
+    with torch.cuda.device(L.device):
+        rc = _lib.lib.scaml_cho_solve_batched_f64(_ptr(L), _ptr(Linv_diag), _ptr(B), _ptr(n_points), T, N, R, _ptr(out),
+                                                  _stream_handle())
+    _lib.check_rc(rc, "scaml_cho_solve_batched_f64")
+    return out
 
 
 def kernel_matrix(X1: torch.Tensor, theta: torch.Tensor, kind: int, X2: Optional[torch.Tensor] = None,
@@ -173,25 +260,38 @@ def source_posteriors(
     n_points: Optional[torch.Tensor] = None,
     want_var: bool = True,
     cov_first: int = 0,
+    keep_V: bool = False,
+    mean_only: bool = False,
 ) -> Dict[str, torch.Tensor]:
-    """Posteriors of all source GPs at the shared query points Xq (M, D).
+    """Posteriors of all source GPs at the shared query points Xq (M, D), or at per-task query sets
+    Xq (T, M, D).  ``mean_only`` skips the triangular solve (mu = m + s K_* alpha only; L and
+    Linv_diag may be None); ``keep_V`` also returns V = L^-1 K_*^T (T, N, M).
 
     Returns dict(mean (T, M), var (T, M) or None, cov (T, cov_first, M) or None): ``cov`` is the
     posterior covariance between the first ``cov_first`` query points and all of them (put the
     target's training points first to get Sigma_nn and Sigma_nq in one go).  Un-standardised with
     y_mean / y_std (T) when given.  Launches scaml_posterior_batched_f64 (+ scaml_posterior_cov_f64).
     """
-    if X.dim() != 3 or Xq.dim() != 2:
-        raise ValueError("X must be (T, N, D) and Xq (M, D)")
+    if X.dim() != 3 or Xq.dim() not in (2, 3):
+        raise ValueError("X must be (T, N, D) and Xq (M, D) or (T, M, D)")
     T, N, D = X.shape
-    M = Xq.shape[0]
-    if Xq.shape[1] != D:
+    M = Xq.shape[-2]
+    if Xq.shape[-1] != D:
         raise ValueError("Xq and X disagree on D")
+    flags = 0
     X = _check(X, "X")
-    Xq = _check(Xq, "Xq")
+    if Xq.dim() == 3:
+        Xq = _check(Xq, "Xq", (T, M, D))
+        flags |= _lib.POST_XQ_PER_TASK
+    else:
+        Xq = _check(Xq, "Xq")
     theta = _check(theta, "theta", (T, D + 2))
-    L = _check(L, "L", (T, N, N))
-    Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
+    if mean_only:
+        flags |= _lib.POST_MEAN_ONLY
+        want_var, cov_first, keep_V, L, Linv_diag = False, 0, False, None, None
+    else:
+        L = _check(L, "L", (T, N, N))
+        Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
     alpha = _check(alpha, "alpha", (T, N))
     if y_mean is not None:
         y_mean = _check(y_mean, "y_mean", (T,))
@@ -205,18 +305,18 @@ def source_posteriors(
     with torch.cuda.device(dev):
         mu = torch.empty((T, M), dtype=torch.float64, device=dev)
         var = torch.empty((T, M), dtype=torch.float64, device=dev) if want_var else None
-        V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if cov_first > 0 else None
+        V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if (cov_first > 0 or keep_V) else None
         rc = _lib.lib.scaml_posterior_batched_f64(
             _ptr(Xq), _ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(y_mean), _ptr(y_std),
-            _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), _stream_handle())
+            _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), flags, _stream_handle())
         _lib.check_rc(rc, "scaml_posterior_batched_f64")
         cov = None
         if cov_first > 0:
             cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)
             rc = _lib.lib.scaml_posterior_cov_f64(_ptr(Xq), _ptr(theta), _ptr(V), _ptr(y_std), T, N, M, cov_first, D,
-                                                  int(kind), _ptr(cov), _stream_handle())
+                                                  int(kind), _ptr(cov), flags & _lib.POST_XQ_PER_TASK, _stream_handle())
             _lib.check_rc(rc, "scaml_posterior_cov_f64")
-    return dict(mean=mu, var=var, cov=cov)
+    return dict(mean=mu, var=var, cov=cov, V=V if keep_V else None)
 
 
 def weighted_task_sum(values: torch.Tensor, weights: torch.Tensor, power: int = 1,

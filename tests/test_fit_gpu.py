@@ -181,5 +181,5 @@ def test_rejects_cpu_tensors_and_wrong_dtype(device):
     with pytest.raises(ValueError):
         ops.gp_fit_fused(X.to(device).float(), y.to(device), theta.to(device), O.KIND_RBF)
     with pytest.raises(ValueError):
-        ops.gp_fit_fused(torch.rand(2, 300, 2, dtype=torch.float64, device=device), torch.rand(2, 300, dtype=torch.float64, device=device),
-                         theta.to(device), O.KIND_RBF)
+        ops.gp_fit_fused(torch.rand(2, 600, 2, dtype=torch.float64, device=device), torch.rand(2, 600, dtype=torch.float64, device=device),
+                         theta.to(device), O.KIND_RBF)   # beyond the two-block limit of 512 points

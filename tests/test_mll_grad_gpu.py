@@ -29,6 +29,8 @@ def _autograd_grad(X, y, theta, kind):
     (2, 100, 5, O.KIND_MATERN52),
     (2, 256, 8, O.KIND_RBF),
     (2, 256, 8, O.KIND_MATERN52),
+    (2, 400, 6, O.KIND_MATERN52),   # two-block fit (N > 256) feeding the same gradient kernels
+    (2, 512, 6, O.KIND_RBF),
 ])
 def test_mll_gradient_matches_autograd(T, N, D, kind, device):
     d = synthetic.smooth_field_task_stack(T, N, D, seed=20 + N)

@@ -155,3 +155,31 @@ def test_target_fit_and_bo_loop_progress(fitted):
     assert float(Y.min()) <= random_best + 5.0   # meta-learned prior should not be (much) worse than random search
     ei = utils.ExpectedImprovement(loop.model, float(Y.min()))(torch.rand(5, 2, dtype=torch.float64))
     assert bool((ei >= 0).all())
+
+
+def test_meta_fit_large_source_tasks_hartmann6(device):
+    """BASELINE config 5 shape (N = 512 source points, D = 6), reduced T and iterations: the stack
+    goes through the two-block fit + the gradient kernels inside the batched L-BFGS."""
+    T, N = 3, 512
+    d = synthetic.hartmann6_task_stack(T, N, seed=3)
+    meta = {t: M.SupervisedDataset(torch.from_numpy(d["X"][t]), torch.from_numpy(d["Y"][t]).unsqueeze(-1)) for t in range(T)}
+    stack = M.SourceGPStack(list(meta.keys()), [v.X() for v in meta.values()], [v.Y() for v in meta.values()], kind=O.KIND_MATERN52)
+    raw0 = stack.raw.clone()
+    f0, g0 = stack.objective(raw0, 1)
+    utils._fit_stack(stack, num_restarts=0, max_iter=15)
+    f1, _ = stack.objective(stack.raw, 1)
+    assert bool((f1 <= f0 + 1e-9).all()) and bool((f1 < f0 - 1e-3).any())
+    bounds = [(1e-4, 1e2)] * 7 + [(1e-8, 1e-2)]
+    for t in range(T):
+        fo, go, _ = O.mll_value_and_grad_raw(stack.X[t].cpu(), stack.y[t].cpu(), raw0[t].cpu(), O.KIND_MATERN52, bounds)
+        np.testing.assert_allclose(-float(f0[t]), float(fo), rtol=1e-3)
+        np.testing.assert_allclose(-g0[t].cpu().numpy(), go.numpy(), rtol=1e-3, atol=1e-6)
+    # posteriors of the refitted stack against the oracle at the fitted hyper-parameters
+    xq = torch.rand(9, 6, dtype=torch.float64)
+    post = stack.posterior(xq)
+    for t in range(T):
+        ref = O.gp_fit(stack.X[t].cpu(), stack.y[t].cpu(), stack.theta[t].cpu(), O.KIND_MATERN52)
+        mu, cov = O.source_posterior(xq, stack.X[t].cpu(), stack.theta[t].cpu(), O.KIND_MATERN52, ref["L"], ref["alpha"],
+                                     float(stack.y_mean[t]), float(stack.y_std[t]))
+        torch.testing.assert_close(post["mean"][t].cpu(), mu, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(post["var"][t].cpu(), torch.diagonal(cov), rtol=1e-4, atol=1e-8)
