@@ -13,17 +13,23 @@
 // in the C/D layout of v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 * reg), and
 // every lane evaluates the kernel function for the four elements it owns straight into it.
 // Waves are specialised: WU "update" waves own tiles; one "panel" wave owns none and factors the
-// 16x16 diagonal blocks.  Per 16-column panel k (diagonal block factored, rows below raw in LDS):
-//   T   owners of column k form L_ik = A_ik W^T with 4 MFMAs per tile (W = L_kk^-1 from the panel
-//       wave), put the final tiles back into the LDS panel and write them to HBM from registers
-//       (128-byte row segments; the mirrored upper tile is written as zeros by the same lanes)
-//   U1  tiles of column k+1 get their rank-16 update first and are spilled to the other LDS panel
-//       (meanwhile the panel wave folds panel k into the running right-hand side y)
-//   U2  all remaining tiles get the rank-16 update (4 MFMAs per tile, operands from the LDS
-//       panel) WHILE the panel wave factors diagonal block k+1 (one-panel lookahead): 16 rank-1
-//       MFMA updates on the symmetric block, the next pivot computed ahead on the VALU so the
-//       64-cycle MFMA latency stays off the pivot chain; a second accumulator receives the same
-//       row operations and ends as L_kk^-1, which also gives v_k = L_kk^-1 y_k as a mat-vec.
+// 16x16 diagonal blocks.  The panel loop is a dataflow pipeline WITHOUT workgroup barriers: the waves
+// hand work to each other through counters in LDS (release/acquire at workgroup scope), so the
+// serial chain of diagonal-block factorisations runs ahead of the bulk update instead of
+// alternating with it.
+//   panel wave, step j:   D_j (diagonal tile with the updates of panels <= j-2, parked in LDS by its
+//       owner) and the raw tile R_j = A[j][j-1] -> L_j,j-1 = R_j W_{j-1}^T and D_j -= L L^T by 8 MFMAs of
+//       its own -> factor D_j (16 rank-1 MFMA updates on the symmetric block, the next pivot formed
+//       ahead on the VALU so the 64-cycle MFMA latency stays off the pivot chain; a second
+//       accumulator receives the same row operations and ends as W_j = L_jj^-1) -> fold the finished
+//       column j-1 into the running right-hand side, v_j = W_j y_j -> publish flagW[j].
+//   update waves, iteration k (after flagW[k]):
+//       T   owners of column k form L_ik = A_ik W_k^T with 4 MFMAs per tile, put the final tiles back
+//           into the LDS panel and write them to HBM from registers (128-byte row segments; the
+//           mirrored upper tile is written as zeros by the same lanes); count cntT[k]
+//       U1  (after every wave's T) column k+1 and the diagonal tile D_{k+2} get their rank-16 update
+//           first and are parked (raw) in LDS for the panel wave; count cntS[k]
+//       U2  all remaining tiles get the rank-16 update (4 MFMAs per tile, operands from the LDS panel).
 // alpha comes from a blocked back-substitution over the L tiles still held in registers.  A
 // failed pivot restarts the task in-kernel with the next jitter (1e-8, 1e-7, 1e-6), as
 // linear_operator's psd_safe_cholesky does on the host.
@@ -38,11 +44,32 @@
 __device__ long long* g_stamp_buf = nullptr;
 #define STAMP_DECL long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[16] = {0}
 #define STAMP(i) do { long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; } while (0)
-#define STAMP_FLUSH(task) do { if (g_stamp_buf && (threadIdx.x == 0 || threadIdx.x == blockDim.x - 64)) for (int i_ = 0; i_ < 16; ++i_) g_stamp_buf[((task) * 2 + (threadIdx.x != 0)) * 16 + i_] = st_acc[i_]; } while (0)
+#ifndef SCAML_STAMP_WAVE
+#define SCAML_STAMP_WAVE 0   // which update wave reports (next to the panel wave)
+#endif
+#define STAMP_FLUSH(task) do { if (g_stamp_buf && (threadIdx.x == 64 * SCAML_STAMP_WAVE || threadIdx.x == blockDim.x - 64)) for (int i_ = 0; i_ < 16; ++i_) g_stamp_buf[((task) * 2 + (threadIdx.x != 64 * SCAML_STAMP_WAVE)) * 16 + i_] = st_acc[i_]; } while (0)
+#ifdef SCAML_STAMPS_PER_PANEL
+// variant: slot k = time (since kernel start) at which panel step k was published / U1(k) was done
+#undef STAMP
+#define STAMP(i)
+#ifdef SCAML_STAMPS_ONE_PANEL
+// variant: absolute times of the sub-steps of one panel iteration (SCAML_STAMPS_ONE_PANEL = k)
+#define STAMP_AT(i)
+#define STAMP_K(kk, i) do { if ((kk) == SCAML_STAMPS_ONE_PANEL) st_acc[i] = __builtin_amdgcn_s_memtime() - st_prev; } while (0)
 #else
+#define STAMP_AT(i) do { st_acc[i] = __builtin_amdgcn_s_memtime() - st_prev; } while (0)
+#endif
+#else
+#define STAMP_AT(i)
+#endif
+#else
+#define STAMP_AT(i)
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH(task)
+#endif
+#ifndef STAMP_K
+#define STAMP_K(kk, i)
 #endif
 
 namespace scaml {
@@ -59,33 +86,47 @@ __device__ __forceinline__ int opaque_s(int v) {
   return v;
 }
 
-// ---- panel wave: Cholesky of the 16x16 diagonal block k, its inverse, and v_k = L_kk^-1 y_k ----
-// panel rows 16k..16k+15 hold the symmetric trailing block (both triangles).  The block sits in
-// one MFMA accumulator (C/D layout); step c scales row c (= column c by symmetry, already in
-// operand position on lane group c & 3), applies the rank-1 update with ONE MFMA and forms the
-// next pivot ahead of it on the VALU, so the 64-cycle MFMA latency is off the pivot chain.  A
-// second accumulator R (initially I) receives the same row operations and ends as W = L_kk^-1.
-// Lanes outside the active group store to a per-lane trash slot instead of being masked off
-// (no exec juggling in the 16-step chain).
-// Outputs: panel rows <- L_kk (zero above the diagonal), Wk[c * PP + j] = W[c][j], vv.
+// ---- wave-to-wave hand-off through LDS counters -------------------------------------------------
+// All waves of the workgroup are resident, so a spinning wave cannot starve the one it waits for;
+// s_sleep keeps the pollers off the issue ports.  Release/acquire at workgroup scope orders the LDS
+// traffic (on gfx950 that is s_waitcnt lgkmcnt(0) around the atomic; HBM stores are not waited for).
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int sync_peek(const int* p) {
+  return __hip_atomic_load((const lds_int_t*)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sync_wait_ge(const int* p, int target) {
+  while (sync_peek(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void sync_arrive(int* p, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void sync_publish(int* p, int value, int lane) {
+  if (lane == 0) __hip_atomic_store((lds_int_t*)p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- panel wave: Cholesky of one 16x16 diagonal block and its inverse ----
+// `a` holds the symmetric trailing block (both triangles) in the MFMA C/D layout.  Step c scales
+// row c (= column c by symmetry, already in operand position on lane group c & 3), applies the
+// rank-1 update with ONE MFMA and forms the next pivot ahead of it on the VALU, so the 64-cycle
+// MFMA latency is off the pivot chain.  A second accumulator R (initially I) receives the same row
+// operations and ends as W = L_kk^-1.  Lanes outside the active group store to a per-lane trash
+// slot instead of being masked off (no exec juggling in the 16-step chain).
+// Outputs: LT[r * PP + c] = L_kk[r][c] (zero above the diagonal), Wk[c * PP + j] = W[c][j].
 // Returns 0 or the 1-based global index of the first non-positive / out-of-range pivot.
-__device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double* vv, double* trash,
-                                               const double* ytil, int k, int lane) {
+__device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, double* trash, int k, int lane) {
   const int lc = lane & 15, lq = lane >> 4;
-  d4_t a, R;
+  d4_t R;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    a[g] = panel[(16 * k + lq + 4 * g) * PP + lc];
-    R[g] = (lc == lq + 4 * g) ? 1.0 : 0.0;
-  }
-  // LDS element offsets relative to `panel` (the trash slot is addressed through the same base)
-  const int off_trash = (int)(trash - panel) + lane;
-  const int off_prow = (16 * k + lc) * PP;    // + c   -> L[lc][c]
-  const int off_w = (int)(Wk - panel) + lc;   // + c*PP -> W[c][lc]
+  for (int g = 0; g < 4; ++g) R[g] = (lc == lq + 4 * g) ? 1.0 : 0.0;
+  // LDS element offsets relative to `LT` (the trash slot is addressed through the same base)
+  const int off_trash = (int)(trash - LT) + lane;
+  const int off_prow = lc * PP;              // + c   -> L[lc][c]
+  const int off_w = (int)(Wk - LT) + lc;     // + c*PP -> W[c][lc]
   // Pivot chain per step: rsqrt(dpiv) -> ri^2 -> next dpiv.  Everything else hangs off it: the raw
   // row values are masked and read across lanes as soon as the previous MFMA lands (before ri is
   // known), the range check only feeds `bad`, the two MFMAs and the LDS stores trail behind.
-  int bad = 0;
+  bool okall = true;
+  double piv[16];
   double dpiv = readlane_f64(a[0], 0);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -94,11 +135,11 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
     const bool low = (unsigned)(lane - (16 * g + c)) < (unsigned)(16 - c);  // mine && lc >= c
     const double am = low ? a[rg] : 0.0;    // raw column c (row c of the symmetric block), masked
     const double Rm = mine ? R[rg] : 0.0;
-#ifndef PROBE_NO_OOB
-    // non-positive, NaN (or too small for the f32-seeded rsqrt): remember the first failing step;
-    // the garbage it produces afterwards is never used
-    if (!(dpiv >= 1e-30) && bad == 0) bad = 16 * k + c + 1;
-#endif
+    // non-positive, NaN (or too small for the f32-seeded rsqrt): one compare per step here, the index
+    // of the first failing step is only worked out if something failed; the garbage a failed step
+    // produces afterwards is never used
+    piv[c] = dpiv;
+    okall = okall & (dpiv >= 1e-30);
     const double ri = rsqrt_seeded(dpiv);
     if (c < 15) {
       const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
@@ -115,18 +156,16 @@ __device__ __forceinline__ int potf2_inv_block(double* panel, double* Wk, double
 #endif
     }
 #ifndef PROBE_NO_STORE
-    panel[mine ? off_prow + c : off_trash] = lcol;
-    panel[mine ? off_w + c * PP : off_trash] = wrow;
+    LT[mine ? off_prow + c : off_trash] = lcol;
+    LT[mine ? off_w + c * PP : off_trash] = wrow;
 #endif
   }
-  // v_k = W y_k: lane (lc, lq) takes the four terms c = 4 lq .. 4 lq + 3 of row lc, then the lane
-  // groups are summed
-  double v = 0.0;
+  int bad = 0;
+  if (!okall) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) v = __builtin_fma(Wk[lc * PP + 4 * lq + c], ytil[16 * k + 4 * lq + c], v);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  if (lq == 0) vv[16 * k + lc] = v;
+    for (int c = 15; c >= 0; --c)
+      if (!(piv[c] >= 1e-30)) bad = 16 * k + c + 1;
+  }
   return bad;
 }
 
@@ -221,11 +260,17 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   static_assert(SLOTS <= 20, "tile_regs.inc provides 20 accumulator tiles");
 
   extern __shared__ double lds[];
-  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][NP][PP] + WAll[NB][16][PP] afterwards
+  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][NP][PP] + WAll[NB][16][PP] +
+  // DG[2][16][PP] + CR[2][16][PP] (parked diagonal / sub-diagonal tiles for the panel wave) +
+  // LT[2][16][PP] (factored diagonal blocks) afterwards
   double* xsT = lds;
   double* PT = lds;
   double* WAll = lds + 2 * PANEL;
-  const int regionA = (p.D * NP > 2 * PANEL + NB * 16 * PP) ? p.D * NP : 2 * PANEL + NB * 16 * PP;
+  double* DG = WAll + NB * 16 * PP;
+  double* CR = DG + 2 * 16 * PP;
+  double* LT = CR + 2 * 16 * PP;
+  constexpr int REGION_A = 2 * PANEL + (NB + 6) * 16 * PP;
+  const int regionA = (p.D * NP > REGION_A) ? p.D * NP : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
   double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
@@ -235,6 +280,10 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   int* rowlist = (int*)(exptab + 64);  // [WU][NB][8]: count, then up to 7 packed (slot << 8 | column) per block row
   double* invl = exptab + 64 + WU * NB * 4;  // [D]  1 / lengthscale
   int* flagp = (int*)(invl + p.D + (p.D & 1));  // [2] fail index
+  int* flagW = flagp + 2;        // [NB] 1: W_k, v_k, L_kk published by the panel wave; 2: failed pivot
+  int* cntT = flagW + NB;        // [NB] update waves done with T(k): column k final in LDS
+  int* cntS = cntT + NB;         // [NB] update waves done with U1(k): column k+1 and D_{k+2} parked
+  int* cntY = cntS + NB;         // [NB] update waves done folding column k into the right-hand side
 
   const int task = blockIdx.x;
   const int tid = threadIdx.x;
@@ -271,6 +320,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();  // previous attempt done with region A
     if (!from_matrix && tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
+    if (tid < 4 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);
     if (!is_panel && lane == 0) {
       // which off-diagonal tiles of each block row this wave holds (for the back-substitution)
@@ -345,8 +395,20 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();  // xsT dead from here: region A becomes PT / WAll
     STAMP(1);
 
-    // ---- prologue: column 0 to LDS, diagonal block 0 factored
+    // ---- prologue: column 0 (raw) to PT[0], the first two diagonal tiles to DG
     fail = 0;
+    // park tile t (index in column-major order over the triangle) at dst[16][PP] if this wave owns it
+    auto park_tile = [&](int t, double* dstbase) {
+      if (t % WU == wave) {
+        const int s = t / WU;
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
+        SCAML_DISPATCH(s)
+#undef SCAML_BODY
+        double* dst = dstbase + lq * PP + lc;
+        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
+      }
+    };
     if (!is_panel) {
       const int s1 = slo(1);
       for (int s = 0; s < s1; ++s) {
@@ -359,24 +421,73 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         SCAML_DISPATCH(s)
 #undef SCAML_BODY
       }
-    }
-    __syncthreads();
-    if (is_panel) {
-      int bad = potf2_inv_block(PT, WAll, vv, trash, ytil, 0, lane);
-      if (bad && lane == 0) flagp[0] = bad;
+      park_tile(off(0), DG);
+      if (NB > 1) {
+        park_tile(off(1), DG + 16 * PP);
+        park_tile(off(0) + 1, CR + 16 * PP);   // R_1 = tile (1, 0)
+      }
     }
     __syncthreads();
     STAMP(2);
-    fail = flagp[0];
 
-    if (!fail) {
-      // Finished tiles of column k: registers -> HBM as 128-byte row segments; the mirrored upper tile is
-      // written as zeros by the same lanes (no separate zero-fill pass over L).
+    if (is_panel) {
+      // ================= panel wave: the chain of diagonal blocks, running ahead of the update =========
+      // (it is the youngest wave on its SIMD and would lose every issue slot to the update wave
+      //  streaming MFMAs next to it: raised priority for the whole chain)
+      __builtin_amdgcn_s_setprio(3);
+      for (int j = 0; j < NB; ++j) {
+        double* Wj = WAll + j * 16 * PP;
+        STAMP_K(j, 0);
+        // D_j (updates of panels <= j-2 applied) and the raw tile R_j = A[j][j-1] were parked by their
+        // owners during U1(j-2): one whole step of slack, the chain does not wait in steady state
+        if (j >= 2) sync_wait_ge(cntS + j - 2, WU);
+        STAMP_K(j, 1);
+        STAMP(3);
+        d4_t a;
+        {
+          const double* dg = DG + (j & 1) * 16 * PP + lq * PP + lc;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) a[g] = dg[4 * g * PP];
+        }
+        if (j >= 1) {
+          // tm = W_{j-1} R_j^T = (L_j,j-1)^T: in the C/D layout that is L_j,j-1 in operand position,
+          // so D_j -= L L^T follows without a transpose through LDS
+          const double* pw = WAll + (j - 1) * 16 * PP + lc * PP + lq;
+          const double* pr = CR + (j & 1) * 16 * PP + lc * PP + lq;
+          d4_t tm = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) tm = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * m], pr[4 * m], tm, 0, 0, 0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[m], tm[m], a, 0, 0, 1);
+        }
+        STAMP(4);
+        STAMP_K(j, 2);
+        double* LTj = LT + (j & 1) * 16 * PP;
+        const int bad = potf2_inv_block(a, LTj, Wj, trash, j, lane);
+        STAMP(5);
+        STAMP_K(j, 3);
+        if (lq == 0) dl[16 * j + lc] = LTj[lc * PP + lc];   // diag(L) for logdet
+        if (bad) {
+          if (lane == 0) flagp[0] = bad;
+          sync_publish(flagW + j, 2, lane);
+          break;
+        }
+        sync_publish(flagW + j, 1, lane);
+        STAMP_K(j, 6);
+        STAMP_AT(j);
+        STAMP(9);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      // ================= update waves ================================================================
+      // Finished sub-diagonal tiles of column k: registers -> HBM as 128-byte row segments; the mirrored
+      // upper tile is written as zeros by the same lanes (no separate zero-fill pass over L).
       auto store_column = [&](int k) {
         if (Lg) {
           const int sa = slo(k), sb = slo(k + 1), offk = off(k);
           for (int s = sa; s < sb; ++s) {
             const int ti = k + (s * WU + wave - offk);
+            if (ti == k) continue;   // the diagonal tile: store_diag
             double e[4];
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
             SCAML_DISPATCH(s)
@@ -384,7 +495,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             {
               double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
               double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
-              if (16 * ti + 16 <= n && ti != k) {                   // interior tile: no per-lane bounds
+              if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                   tb[(size_t)g * 4 * N + lane_idx] = e[g];
@@ -395,110 +506,164 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                   const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;
-                  if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                  if (zero_upper && ti != k && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+                  if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                  if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
                 }
               }
             }
           }
         }
       };
+      // L_kk left its owner's registers long ago: it comes from the panel wave's LDS copy LT[k & 1], which
+      // step k+2 overwrites once cntS[k] is complete -- so this runs before the wave's arrival there
+      auto store_diag = [&](int k) {
+        if (Lg && off(k) % WU == wave) {
+          const double* lt = LT + (k & 1) * 16 * PP + lq * PP + lc;
+          double* tb = Lg + ((size_t)(16 * k) * N + 16 * k);
+          const int col = 16 * k + lc;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * k + lq + 4 * g;
+            const double e = lt[4 * g * PP];
+            if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e;
+          }
+        }
+      };
       for (int k = 0; k < NB; ++k) {
-        double* buf = PT + (k & 1) * PANEL;         // panel k: diagonal block final, rows below raw
-        double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1
+        double* buf = PT + (k & 1) * PANEL;         // column k: raw sub-diagonal tiles, final after T(k)
+        double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1 (raw)
         const double* Wk = WAll + k * 16 * PP;
-        if (!is_panel) {
+        int fw;
+        STAMP_K(k, 0);
+        while ((fw = sync_peek(flagW + k)) == 0) __builtin_amdgcn_s_sleep(1);
+        STAMP_K(k, 1);
+        STAMP(3);
+        if (fw == 2) break;
+#ifndef SCAML_NO_TPRIO
+        // T and U1 are short and latency-critical (the panel wave waits for their results): same
+        // priority as the panel wave, so that its SIMD-mate is not starved exactly here
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        {
           const int sa = slo(k), sb = slo(k + 1), offk = off(k);
-          // T(k): column k becomes final.  Sub-diagonal tiles: L_ik = A_ik W^T (4 MFMAs, A rows from the
-          // panel, W = L_kk^-1); the diagonal tile is read back from the panel.
+          if (sa < sb) {
+            // forward substitution rides along: v_k = W_k y_k, formed (redundantly, identical values) by
+            // every wave that holds a tile of column k; y_k is complete once column k-1 has been folded
+            if (k >= 1) sync_wait_ge(cntY + k - 1, WU);
+            double v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v = __builtin_fma(Wk[lc * PP + 4 * lq + c], ytil[16 * k + 4 * lq + c], v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lq == 0) vv[16 * k + lc] = v;
+          }
+          // T(k): column k becomes final: L_ik = A_ik W^T (4 MFMAs, A rows raw from the panel, W = L_kk^-1)
           for (int s = sa; s < sb; ++s) {
             const int ti = k + (s * WU + wave - offk);
+            if (ti == k) continue;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
-            if (ti == k) {                                                                         \
-              const double* prow = buf + (16 * ti + lq) * PP + lc;                                 \
-              TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]); \
-            } else {                                                                               \
-              const double* pa = buf + (16 * ti + lc) * PP + lq;                                   \
-              const double* pw = Wk + lc * PP + lq;                                                \
-              TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]); \
-            }
+            const double* pa = buf + (16 * ti + lc) * PP + lq;                                     \
+            const double* pw = Wk + lc * PP + lq;                                                  \
+            TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
           }
           MFMA_DRAIN();
+          STAMP_K(k, 2);
           // final tiles: back to the panel for everyone's operand reads
           for (int s = sa; s < sb; ++s) {
             const int ti = k + (s * WU + wave - offk);
+            if (ti == k) continue;
             double e[4];
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
-            if (ti != k) {
-              double* prow = buf + (16 * ti + lq) * PP + lc;
-              prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];
-            } else {
+            double* prow = buf + (16 * ti + lq) * PP + lc;
+            prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];
+          }
+          STAMP_K(k, 3);
+          sync_arrive(cntT + k, lane);
+          STAMP_K(k, 4);
+          // running right-hand side: y_i -= L_ik v_k, as an MFMA product with v_k broadcast over the
+          // columns (every column of the result is L_ik v_k); each row of y has one owner per column k.
+          // (done while the slower waves finish their T)
+          for (int s = sa; s < sb; ++s) {
+            const int ti = k + (s * WU + wave - offk);
+            if (ti == k) continue;
+            const double* pa = buf + (16 * ti + lc) * PP + lq;
+            const double* pv = vv + 16 * k + lq;
+            d4_t lv = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-              for (int g = 0; g < 4; ++g)
-                if (lc == lq + 4 * g) dl[16 * k + lc] = e[g];
+            for (int m = 0; m < 4; ++m) lv = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * m], pv[4 * m], lv, 0, 0, 0);
+            if (lc < 4) {
+              const double part = lc == 0 ? lv[0] : (lc == 1 ? lv[1] : (lc == 2 ? lv[2] : lv[3]));
+              ytil[16 * ti + lq + 4 * lc] -= part;
             }
           }
+          STAMP_K(k, 5);
+          sync_arrive(cntY + k, lane);
+          STAMP_K(k, 6);
+          store_diag(k);
         }
-        // (issuing these stores after barrier X instead — off the critical path — measured 4 % slower:
-        //  they then compete with the bulk update for issue slots; interleaved A/B, tools/dev_ab.py)
-        if (!is_panel) store_column(k);
-        STAMP(3);
-        __syncthreads();  // Z: panel k final in LDS
         STAMP(4);
-        if (k + 1 == NB) break;
-        if (is_panel) {
-          // running right-hand side: y_r -= L[r, panel k] . v_k for every row below the block
-          double vk[16];
-          const double vmine = vv[16 * k + lc];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) vk[c] = readlane_f64(vmine, c);
-          for (int r = 16 * (k + 1) + lane; r < NP; r += 64) {
-            const double* pr = buf + r * PP;
-            double yr = ytil[r];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) yr = __builtin_fma(-pr[c], vk[c], yr);
-            ytil[r] = yr;
-          }
-        } else {
-          // U1: column k+1 first: rank-16 update, then spill (raw) to the other panel buffer
+        if (k + 1 == NB) { __builtin_amdgcn_s_setprio(0); store_column(k); break; }
+        sync_wait_ge(cntT + k, WU);   // column k final in LDS (and everyone is done reading column k-1)
+        STAMP_K(k, 7);
+        STAMP(5);
+        {
+          // U1: column k+1 and the diagonal tile D_{k+2} first: rank-16 update, then parked (raw) in LDS
           const int sa = slo(k + 1), sb = slo(k + 2), offk1 = off(k + 1);
           const double* pb = buf + (16 * (k + 1) + lc) * PP + lq;
           for (int s = sa; s < sb; ++s) {
             const int ti = k + 1 + (s * WU + wave - offk1);
+            if (ti == k + 1) continue;   // D_{k+1} left during U1(k-1)
             const double* pa = buf + (16 * ti + lc) * PP + lq;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) \
             TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
           }
+          const int td = off(k + 2);     // tile (k+2, k+2)
+          const bool own_d = k + 2 < NB && td % WU == wave;
+          if (own_d) {
+            const int s = td / WU;
+            const double* pd = buf + (16 * (k + 2) + lc) * PP + lq;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) \
+            TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pd[0], pd[4], pd[8], pd[12], pd[0], pd[4], pd[8], pd[12]);
+            SCAML_DISPATCH(s)
+#undef SCAML_BODY
+          }
           MFMA_DRAIN();
+          STAMP_K(k, 8);
           for (int s = sa; s < sb; ++s) {
             const int ti = k + 1 + (s * WU + wave - offk1);
+            if (ti == k + 1) continue;
             double e0, e1, e2, e3;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
             double* dst = nbuf + (16 * ti + lq) * PP + lc;
             dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
+            if (ti == k + 2) {   // R_{k+2}: a second copy where T(k+1) will not overwrite it
+              double* cr = CR + (k & 1) * 16 * PP + lq * PP + lc;
+              cr[0] = e0; cr[4 * PP] = e1; cr[8 * PP] = e2; cr[12 * PP] = e3;
+            }
           }
+          if (own_d) park_tile(td, DG + (k & 1) * 16 * PP);
         }
-        STAMP(5);
-        __syncthreads();  // X: column k+1 (raw) and the updated right-hand side visible to the panel wave
+        STAMP_K(k, 9);
+        sync_arrive(cntS + k, lane);
+        __builtin_amdgcn_s_setprio(0);
+        STAMP_K(k, 10);
+        STAMP_AT(k);
+        // (issuing these stores after the bulk update instead measured 4 % slower in the barrier version:
+        //  they then compete with the MFMA stream for issue slots; interleaved A/B, tools/dev_ab.py)
+        store_column(k);
+        STAMP_K(k, 11);
         STAMP(6);
-        if (is_panel) {
-          // the panel wave is the youngest wave on its SIMD and would lose every issue slot to the
-          // update wave streaming MFMAs next to it: raise its priority for the pivot chain
-          __builtin_amdgcn_s_setprio(3);
-          int bad = potf2_inv_block(nbuf, WAll + (k + 1) * 16 * PP, vv, trash, ytil, k + 1, lane);
-          __builtin_amdgcn_s_setprio(0);
-          if (bad && lane == 0) flagp[0] = bad;
-        } else {
-          // U2: the bulk of the trailing update, overlapped with the panel wave: every slot from
-          // slo(k+2) on, entered through one switch and then falling through slot after slot
+        {
+          // U2: the bulk of the trailing update: every slot from slo(k+2) on, entered through one switch
+          // and then falling through slot after slot (the parked D_{k+2} is skipped)
           const int s0 = slo(k + 2);
           int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
 #define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
@@ -506,9 +671,11 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             if (S < SLOTS) {                                                                       \
               while (uj < NB && ur >= NB - uj) { ur -= NB - uj; ++uj; }                            \
               if (uj < NB) {                                                                       \
-                const double* pa = buf + (16 * (uj + ur) + lc) * PP + lq;                          \
-                const double* pb = buf + (16 * uj + lc) * PP + lq;                                 \
-                TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+                if (ur != 0 || uj != k + 2) {                                                      \
+                  const double* pa = buf + (16 * (uj + ur) + lc) * PP + lq;                        \
+                  const double* pb = buf + (16 * uj + lc) * PP + lq;                               \
+                  TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+                }                                                                                  \
                 ur += WU;                                                                          \
               }                                                                                    \
             }
@@ -516,18 +683,16 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_U2_
           MFMA_DRAIN();
         }
+        STAMP_K(k, 12);
         STAMP(7);
-        __syncthreads();  // Y: diagonal block k+1 factored
-        STAMP(8);
-        fail = flagp[0];
-        if (fail) break;
       }
     }
   }
+  __syncthreads();
+  fail = flagp[0];
 
   // ---- scalars: quad, logdet (panel wave), then alpha by blocked back-substitution
-  __syncthreads();
-  STAMP(9);
+  STAMP(15);
   if (!fail) {
     if (is_panel) {
       double q = 0.0, ld = 0.0;

@@ -4,7 +4,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from scamlgp_amd import synthetic
-lib = ctypes.CDLL(os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd", "lib", "libscaml_hip_stamps.so"))
+ONE = [a for a in sys.argv if a.startswith("--one-panel")]
+if ONE:
+    sys.argv.remove(ONE[0])
+PER_PANEL = "--per-panel" in sys.argv
+if PER_PANEL:
+    sys.argv.remove("--per-panel")
+lib = ctypes.CDLL(os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd", "lib", ("libscaml_hip_onepanel%s.so" % ONE[0][len("--one-panel"):]) if ONE else ("libscaml_hip_perpanel.so" if PER_PANEL else "libscaml_hip_stamps.so")))
 vp = ctypes.c_void_p
 lib.scaml_gp_fit_fused_f64.argtypes = [vp]*5 + [ctypes.c_int]*4 + [vp]*8 + [ctypes.c_uint, vp]
 lib.scaml_debug_set_stamp_buffer.argtypes = [vp]
@@ -20,13 +26,33 @@ q, ld, mll, jit = (torch.empty(T, dtype=torch.float64, device=dev) for _ in rang
 stamps = torch.zeros(T, 2, 16, dtype=torch.int64, device=dev)
 assert lib.scaml_debug_set_stamp_buffer(stamps.data_ptr()) == 0
 for _ in range(3):
-    rc = lib.scaml_gp_fit_fused_f64(X.data_ptr(), y.data_ptr(), th.data_ptr(), None, None, T, N, D, kind, L.data_ptr(), alpha.data_ptr(), q.data_ptr(), ld.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(), None, 3, None)
+    rc = lib.scaml_gp_fit_fused_f64(X.data_ptr(), y.data_ptr(), th.data_ptr(), None, None, T, N, D, kind, L.data_ptr(), alpha.data_ptr(), q.data_ptr(), ld.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(), None, 1, None)
     assert rc == 0
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
-names = ["load X,y", "K-build", "prologue (spill0+potf2)", "T: trsm+final stores", "Z barrier wait", "U1: col k+1 upd+spill", "X barrier wait", "U2: bulk update", "Y barrier wait (potf2)", "loop exit barrier", "tail: rest", "tail: scalars+copy+bar", "backsub: matvec", "backsub: tiles", "backsub: barrier"]
-med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0); tot = med[:15].sum()
-print(f"{'phase':26s} {'update wave 0':>14s} {'panel wave':>12s}")
-for i, nm in enumerate(names):
-    print(f"{nm:26s} {med[i]:10.0f} cyc  {100*med[i]/tot:5.1f}%  {medp[i]:10.0f}")
-print(f"total {tot:.0f} shader cycles (update wave 0 timeline) ~ {tot/2.4e3:.1f} us at 2.4 GHz")
+if ONE:
+    med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0)
+    nu = ["iter start", "flagW seen", "TRSM done+drain", "final tiles in LDS", "arrived cntT", "fold done", "arrived cntY", "cntT complete", "U1 mfma+drain", "parked", "arrived cntS", "stores issued", "U2 done"]
+    npn = ["step start", "cntS[j-2] seen", "own TRSM+diag upd", "potf2 done", "cntY[j-1] seen", "v_j done", "pre-read + publish"]
+    for i in range(13):
+        print(f"{nu[i]:22s} {med[i]:10.0f} {med[i]-(med[i-1] if i else med[0]):8.0f}   | " + (f"{npn[i]:22s} {medp[i]:10.0f} {medp[i]-(medp[i-1] if i else medp[0]):8.0f}" if i < 7 else ""))
+    sys.exit(0)
+if PER_PANEL:
+    med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0)
+    print("k   U1(k) done (update wave 0)   delta   | flagW[k] published (panel wave)   delta")
+    for k in range(16):
+        print(f"{k:2d} {med[k]:12.0f} {med[k]-(med[k-1] if k else 0):8.0f}   | {medp[k]:12.0f} {medp[k]-(medp[k-1] if k else 0):8.0f}")
+    sys.exit(0)
+# stamp slots: 0-2 common; 3-9 differ per role; 10-15 tail
+names_u = {0: "load X,y", 1: "K-build", 2: "prologue (park tiles)", 3: "wait flagW[k]", 4: "T: trsm + stores", 5: "wait cntT[k]",
+           6: "U1: col k+1, D_k+2 + park", 7: "U2: bulk update", 15: "loop exit barrier", 11: "tail: scalars+copy+bar",
+           12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
+names_p = {0: "load X,y", 1: "(K-build: idle)", 2: "prologue", 3: "wait cntS[j-2] (D_j)", 4: "own TRSM + diag update", 5: "potf2",
+           6: "wait cntT[j-1]", 7: "fold + v_j", 8: "wait cntS[j-1] + pre-read", 9: "publish + diag store", 15: "loop exit barrier",
+           11: "tail: scalars+copy+bar", 12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
+med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0); tot = med.sum(); totp = medp.sum()
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 11, 12, 13, 14, 10]
+print(f"{'update wave 0':30s} {'cycles':>9s} {'%':>6s}   | {'panel wave':30s} {'cycles':>9s} {'%':>6s}")
+for i in order:
+    print(f"{names_u.get(i, '-'):30s} {med[i]:9.0f} {100*med[i]/tot:5.1f}%   | {names_p.get(i, '-'):30s} {medp[i]:9.0f} {100*medp[i]/totp:5.1f}%")
+print(f"total {tot:.0f} / {totp:.0f} s_memtime ticks (update wave 0 / panel wave timeline)")
