@@ -7,29 +7,32 @@
 //   scamlgp/model.py:176-188 -> scamlgp/utils.py:171-177 -> gpytorch ExactMarginalLogLikelihood
 //   -> linear_operator psd_safe_cholesky -> torch.linalg.cholesky_ex / solve_triangular.
 //
-// Design (DESIGN.md §3).  The kernel matrix never exists in memory: the trailing matrix of a
+// Design (DESIGN.md §3, §4).  The kernel matrix never exists in memory: the trailing matrix of a
 // right-looking Cholesky lives in MFMA accumulator registers.  The lower triangle is cut into
-// 16x16 tiles; tile t (column-major over the triangle) belongs to update wave t % WU, slot t / WU,
-// in the C/D layout of v_mfma_f64_16x16x4_f64 (col = lane & 15, row = (lane >> 4) + 4 * reg), and
-// every lane evaluates the kernel function for the four elements it owns straight into it.
+// 16x16 tiles; tile t (column-major over the triangle) belongs to update wave t % WU, slot t / WU.
+// A tile is held TRANSPOSED in the C/D layout of v_mfma_f64_16x16x4_f64: lane (lc = lane & 15,
+// lq = lane >> 4) register g holds A[16 i + lc][16 j + lq + 4 g] -- the lane owns a piece of a ROW.
+// That makes the accumulator registers themselves the B operand of W * A^T, so the triangular solve
+// of a column (L_ik = A_ik W_k^T, W_k = L_kk^-1) runs on the tile where it sits, without a trip
+// through LDS, and the forward-substitution dot products are in-lane.
 // Waves are specialised: WU "update" waves own tiles; one "panel" wave owns none and factors the
 // 16x16 diagonal blocks.  The panel loop is a dataflow pipeline WITHOUT workgroup barriers: the waves
-// hand work to each other through counters in LDS (release/acquire at workgroup scope), so the
-// serial chain of diagonal-block factorisations runs ahead of the bulk update instead of
-// alternating with it.
-//   panel wave, step j:   D_j (diagonal tile with the updates of panels <= j-2, parked in LDS by its
-//       owner) and the raw tile R_j = A[j][j-1] -> L_j,j-1 = R_j W_{j-1}^T and D_j -= L L^T by 8 MFMAs of
-//       its own -> factor D_j (16 rank-1 MFMA updates on the symmetric block, the next pivot formed
-//       ahead on the VALU so the 64-cycle MFMA latency stays off the pivot chain; a second
-//       accumulator receives the same row operations and ends as W_j = L_jj^-1) -> fold the finished
-//       column j-1 into the running right-hand side, v_j = W_j y_j -> publish flagW[j].
-//   update waves, iteration k (after flagW[k]):
-//       T   owners of column k form L_ik = A_ik W_k^T with 4 MFMAs per tile, put the final tiles back
-//           into the LDS panel and write them to HBM from registers (128-byte row segments; the
-//           mirrored upper tile is written as zeros by the same lanes); count cntT[k]
-//       U1  (after every wave's T) column k+1 and the diagonal tile D_{k+2} get their rank-16 update
-//           first and are parked (raw) in LDS for the panel wave; count cntS[k]
-//       U2  all remaining tiles get the rank-16 update (4 MFMAs per tile, operands from the LDS panel).
+// hand work to each other through counters in LDS (release/acquire at workgroup scope).
+//   panel wave, step j:   D_j (diagonal tile with the updates of panels <= j-2) and the raw tile
+//       R_j = A[j][j-1], both parked in LDS by their owners during U1(j-2) -> L_j,j-1 = R_j W_{j-1}^T and
+//       D_j -= L L^T by 8 MFMAs of its own -> factor D_j (16 rank-1 MFMA updates on the symmetric
+//       block, the next pivot formed ahead on the VALU so the 64-cycle MFMA latency stays off the
+//       pivot chain; a second accumulator receives the same row operations and ends as
+//       W_j = L_jj^-1) -> publish flagW[j].  It runs ahead of the update waves.
+//   update waves, iteration k (column k final in LDS = cntT[k] complete):
+//       U1  column k+1 and the diagonal tile D_{k+2} get the rank-16 update of panel k first; D_{k+2}
+//           and R_{k+2} are parked for the panel wave (cntS[k])
+//       F   (after flagW[k+1]) column k+1 is finalised in registers (4 MFMAs per tile), written to
+//           the LDS panel for everyone's operand reads (cntT[k+1]) and folded into the running
+//           right-hand side; v_{k+1} = W y rides along
+//       U2  all remaining tiles get the rank-16 update of panel k (4 MFMAs per tile, operands from
+//           the LDS panel) -- the bulk, during which the other waves' F(k+1) results arrive
+//       then column k+1 goes to HBM (128-byte row segments; the mirrored upper tile as zeros).
 // alpha comes from a blocked back-substitution over the L tiles still held in registers.  A
 // failed pivot restarts the task in-kernel with the next jitter (1e-8, 1e-7, 1e-6), as
 // linear_operator's psd_safe_cholesky does on the host.
@@ -96,6 +99,14 @@ __device__ __forceinline__ int sync_peek(const int* p) {
 }
 __device__ __forceinline__ void sync_wait_ge(const int* p, int target) {
   while (sync_peek(p) < target) __builtin_amdgcn_s_sleep(1);
+}
+// waiting side of a hand-off that may never come because the panel wave hit a bad pivot
+__device__ __forceinline__ bool sync_wait_ge_or_fail(const int* p, int target, const int* failp) {
+  while (sync_peek(p) < target) {
+    if (sync_peek(failp) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
 }
 __device__ __forceinline__ void sync_arrive(int* p, int lane) {
   if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -236,7 +247,35 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, d
                : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3)            \
                : SCAML_CLOB8(r0, r1, r2, r3, r4, r5, r6, r7))
 
+// out (VGPR tile) = W * tile^T-operand: the accumulator registers of the (transposed) tile are the B
+// operand, k-step m reads register pair m; w0..w3 = W[lc][lq + 4m].  The result is the finalised
+// tile in the same transposed layout.  Ends drained (the VALU may read `out`).
+#define TILE_TRSM_TO_V(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, out)                        \
+  asm volatile("s_nop 1\n\t"                                                                     \
+               "v_mfma_f64_16x16x4_f64 %0, %1, a[" #r0 ":" #r1 "], 0\n\t"                         \
+               "v_mfma_f64_16x16x4_f64 %0, %2, a[" #r2 ":" #r3 "], %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, %3, a[" #r4 ":" #r5 "], %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, %4, a[" #r6 ":" #r7 "], %0\n\t"                        \
+               "s_nop 15\n\ts_nop 2"                                                              \
+               : "=&v"(out)                                                                        \
+               : "v"(w0), "v"(w1), "v"(w2), "v"(w3))
+
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
+
+// sum over the 16 lanes of a DPP row (same lq): the total lands in lane lc == 15
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_sum_to_lane15(double x) {
+  x += dpp_mov_f64<0x118>(x);   // row_shr:8
+  x += dpp_mov_f64<0x114>(x);   // row_shr:4
+  x += dpp_mov_f64<0x112>(x);   // row_shr:2
+  x += dpp_mov_f64<0x111>(x);   // row_shr:1
+  return x;
+}
 
 // switch-dispatch of one runtime slot index onto the code for the matching physical tile
 #define SCAML_CASE_(S, r0, r1, r2, r3, r4, r5, r6, r7) \
@@ -261,15 +300,15 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 
   extern __shared__ double lds[];
   // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][NP][PP] + WAll[NB][16][PP] +
-  // DG[2][16][PP] + CR[2][16][PP] (parked diagonal / sub-diagonal tiles for the panel wave) +
+  // DG[2][256] + CR[2][256] (parked diagonal / sub-diagonal tiles for the panel wave, register image) +
   // LT[2][16][PP] (factored diagonal blocks) afterwards
   double* xsT = lds;
   double* PT = lds;
   double* WAll = lds + 2 * PANEL;
   double* DG = WAll + NB * 16 * PP;
-  double* CR = DG + 2 * 16 * PP;
-  double* LT = CR + 2 * 16 * PP;
-  constexpr int REGION_A = 2 * PANEL + (NB + 6) * 16 * PP;
+  double* CR = DG + 2 * 256;
+  double* LT = CR + 2 * 256;
+  constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
   const int regionA = (p.D * NP > REGION_A) ? p.D * NP : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
@@ -284,6 +323,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   int* cntT = flagW + NB;        // [NB] update waves done with T(k): column k final in LDS
   int* cntS = cntT + NB;         // [NB] update waves done with U1(k): column k+1 and D_{k+2} parked
   int* cntY = cntS + NB;         // [NB] update waves done folding column k into the right-hand side
+  int* cntU = cntY + NB;         // [NB] update waves done with U2(k): nobody reads column k any more
 
   const int task = blockIdx.x;
   const int tid = threadIdx.x;
@@ -320,7 +360,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();  // previous attempt done with region A
     if (!from_matrix && tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
-    if (tid < 4 * NB) flagW[tid] = 0;
+    if (tid < 5 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);
     if (!is_panel && lane == 0) {
       // which off-diagonal tiles of each block row this wave holds (for the back-substitution)
@@ -355,12 +395,12 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       if (S < SLOTS) {                                                                             \
         while (kj < NB && kr >= NB - kj) { kr -= NB - kj; ++kj; }                                  \
         if (kj < NB) {                                                                             \
-          const int col = 16 * kj + lc;                                                            \
-          const int row0 = 16 * (kj + kr) + lq;                                                    \
+          const int row = 16 * (kj + kr) + lc;   /* transposed tile: the lane owns a row piece */  \
+          const int col0 = 16 * kj + lq;                                                           \
           double kt[4];                                                                            \
           if (from_matrix) {                                                                       \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
-              const int row = row0 + 4 * g;                                                        \
+              const int col = col0 + 4 * g;                                                        \
               double kv = 0.0;                                                                     \
               if (row < n && col < n) kv = row >= col ? Ag[(size_t)row * N + col] : Ag[(size_t)col * N + row]; \
               if (row == col) kv += diag_add;                                                      \
@@ -371,14 +411,14 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                   \
             _Pragma("unroll 2") for (int d = 0; d < D; ++d) {                                      \
               const double* xr = xsT + d * NP;                                                     \
-              const double xc = xr[col];                                                           \
+              const double xc = xr[row];                                                           \
               _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                double df = xr[row0 + 4 * g] - xc;                                                 \
+                double df = xr[col0 + 4 * g] - xc;                                                 \
                 d2[g] = __builtin_fma(df, df, d2[g]);                                              \
               }                                                                                    \
             }                                                                                      \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
-              const int row = row0 + 4 * g;                                                        \
+              const int col = col0 + 4 * g;                                                        \
               double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);                            \
               if (row == col) kv += diag_add;                                                      \
               if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                               \
@@ -395,36 +435,25 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();  // xsT dead from here: region A becomes PT / WAll
     STAMP(1);
 
-    // ---- prologue: column 0 (raw) to PT[0], the first two diagonal tiles to DG
+    // ---- prologue: the first two diagonal tiles and R_1 = tile (1, 0) parked for the panel wave
     fail = 0;
-    // park tile t (index in column-major order over the triangle) at dst[16][PP] if this wave owns it
-    auto park_tile = [&](int t, double* dstbase) {
+    // park tile t (index in column-major order over the triangle) as a register image at dst[256] if
+    // this wave owns it
+    auto park_tile = [&](int t, double* dst) {
       if (t % WU == wave) {
         const int s = t / WU;
         double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
         SCAML_DISPATCH(s)
 #undef SCAML_BODY
-        double* dst = dstbase + lq * PP + lc;
-        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
+        dst[lane] = e0; dst[64 + lane] = e1; dst[128 + lane] = e2; dst[192 + lane] = e3;
       }
     };
     if (!is_panel) {
-      const int s1 = slo(1);
-      for (int s = 0; s < s1; ++s) {
-        const int ti = s * WU + wave;
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
-        double e0, e1, e2, e3;                                                                     \
-        TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);                                  \
-        double* dst = PT + (16 * ti + lq) * PP + lc;                                               \
-        dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
-        SCAML_DISPATCH(s)
-#undef SCAML_BODY
-      }
       park_tile(off(0), DG);
       if (NB > 1) {
-        park_tile(off(1), DG + 16 * PP);
-        park_tile(off(0) + 1, CR + 16 * PP);   // R_1 = tile (1, 0)
+        park_tile(off(1), DG + 256);
+        park_tile(off(0) + 1, CR + 256);   // R_1 = tile (1, 0)
       }
     }
     __syncthreads();
@@ -445,18 +474,18 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         STAMP(3);
         d4_t a;
         {
-          const double* dg = DG + (j & 1) * 16 * PP + lq * PP + lc;
+          const double* dg = DG + (j & 1) * 256 + lane;   // symmetric: the transposed image is the block
 #pragma unroll
-          for (int g = 0; g < 4; ++g) a[g] = dg[4 * g * PP];
+          for (int g = 0; g < 4; ++g) a[g] = dg[64 * g];
         }
         if (j >= 1) {
           // tm = W_{j-1} R_j^T = (L_j,j-1)^T: in the C/D layout that is L_j,j-1 in operand position,
           // so D_j -= L L^T follows without a transpose through LDS
           const double* pw = WAll + (j - 1) * 16 * PP + lc * PP + lq;
-          const double* pr = CR + (j & 1) * 16 * PP + lc * PP + lq;
+          const double* pr = CR + (j & 1) * 256 + lane;   // register image of the transposed tile = R[lc][lq + 4m]
           d4_t tm = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int m = 0; m < 4; ++m) tm = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * m], pr[4 * m], tm, 0, 0, 0);
+          for (int m = 0; m < 4; ++m) tm = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * m], pr[64 * m], tm, 0, 0, 0);
 #pragma unroll
           for (int m = 0; m < 4; ++m) a = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[m], tm[m], a, 0, 0, 1);
         }
@@ -480,146 +509,72 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       __builtin_amdgcn_s_setprio(0);
     } else {
       // ================= update waves ================================================================
-      // Finished sub-diagonal tiles of column k: registers -> HBM as 128-byte row segments; the mirrored
-      // upper tile is written as zeros by the same lanes (no separate zero-fill pass over L).
-      auto store_column = [&](int k) {
+      // Finished sub-diagonal tiles of column c: read back from the LDS panel in row segments -> HBM as
+      // 128-byte stores; the mirrored upper tile is written as zeros by the same lanes (no separate
+      // zero-fill pass over L).
+      auto store_column = [&](int c) {
         if (Lg) {
-          const int sa = slo(k), sb = slo(k + 1), offk = off(k);
+          const double* buf = PT + (c & 1) * PANEL;
+          const int sa = slo(c), sb = slo(c + 1), offc = off(c);
           for (int s = sa; s < sb; ++s) {
-            const int ti = k + (s * WU + wave - offk);
-            if (ti == k) continue;   // the diagonal tile: store_diag
-            double e[4];
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
-            SCAML_DISPATCH(s)
-#undef SCAML_BODY
-            {
-              double* tb = Lg + ((size_t)(16 * ti) * N + 16 * k);   // tile (ti, k), wave-uniform
-              double* mb = Lg + ((size_t)(16 * k) * N + 16 * ti);   // mirrored tile (k, ti)
-              if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
+            const int ti = c + (s * WU + wave - offc);
+            if (ti == c) continue;   // the diagonal tile: store_diag
+            const double* prow = buf + (16 * ti + lq) * PP + lc;
+            const double e[4] = {prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]};
+            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c);   // tile (ti, c), wave-uniform
+            double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti);   // mirrored tile (c, ti)
+            if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                  if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-                }
-              } else {
-                const int col = 16 * k + lc, mc = 16 * ti + lc;
+              for (int g = 0; g < 4; ++g) {
+                tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+              }
+            } else {
+              const int col = 16 * c + lc, mc = 16 * ti + lc;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                  const int row = 16 * ti + lq + 4 * g, mr = 16 * k + lq + 4 * g;
-                  if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                  if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-                }
+              for (int g = 0; g < 4; ++g) {
+                const int row = 16 * ti + lq + 4 * g, mr = 16 * c + lq + 4 * g;
+                if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
+                if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
               }
             }
           }
         }
       };
-      // L_kk left its owner's registers long ago: it comes from the panel wave's LDS copy LT[k & 1], which
-      // step k+2 overwrites once cntS[k] is complete -- so this runs before the wave's arrival there
-      auto store_diag = [&](int k) {
-        if (Lg && off(k) % WU == wave) {
-          const double* lt = LT + (k & 1) * 16 * PP + lq * PP + lc;
-          double* tb = Lg + ((size_t)(16 * k) * N + 16 * k);
-          const int col = 16 * k + lc;
+      // L_cc left its owner's registers long ago: it comes from the panel wave's LDS copy LT[c & 1], which
+      // step c+2 overwrites once cntS[c] is complete -- so this runs before the wave's arrival there
+      auto store_diag = [&](int c) {
+        if (Lg && off(c) % WU == wave) {
+          const double* lt = LT + (c & 1) * 16 * PP + lq * PP + lc;
+          double* tb = Lg + ((size_t)(16 * c) * N + 16 * c);
+          const int col = 16 * c + lc;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int row = 16 * k + lq + 4 * g;
+            const int row = 16 * c + lq + 4 * g;
             const double e = lt[4 * g * PP];
             if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e;
           }
         }
       };
-      for (int k = 0; k < NB; ++k) {
-        double* buf = PT + (k & 1) * PANEL;         // column k: raw sub-diagonal tiles, final after T(k)
-        double* nbuf = PT + ((k + 1) & 1) * PANEL;  // receives column k+1 (raw)
-        const double* Wk = WAll + k * 16 * PP;
-        int fw;
-        STAMP_K(k, 0);
-        while ((fw = sync_peek(flagW + k)) == 0) __builtin_amdgcn_s_sleep(1);
-        STAMP_K(k, 1);
-        STAMP(3);
-        if (fw == 2) break;
-#ifndef SCAML_NO_TPRIO
-        // T and U1 are short and latency-critical (the panel wave waits for their results): same
-        // priority as the panel wave, so that its SIMD-mate is not starved exactly here
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        {
-          const int sa = slo(k), sb = slo(k + 1), offk = off(k);
-          if (sa < sb) {
-            // forward substitution rides along: v_k = W_k y_k, formed (redundantly, identical values) by
-            // every wave that holds a tile of column k; y_k is complete once column k-1 has been folded
-            if (k >= 1) sync_wait_ge(cntY + k - 1, WU);
-            double v = 0.0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v = __builtin_fma(Wk[lc * PP + 4 * lq + c], ytil[16 * k + 4 * lq + c], v);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (lq == 0) vv[16 * k + lc] = v;
-          }
-          // T(k): column k becomes final: L_ik = A_ik W^T (4 MFMAs, A rows raw from the panel, W = L_kk^-1)
+      // iteration k = -1 only finalises column 0
+      for (int k = -1; k + 1 < NB; ++k) {
+        const int c = k + 1;                          // the column finalised in this iteration
+        const double* buf = PT + (k & 1) * PANEL;     // column k, final (operand reads)
+        double* cbuf = PT + (c & 1) * PANEL;          // receives column c
+        if (k >= 0) {
+          // (every wait below gives up when the panel wave has reported a failed pivot: the waves it is
+          //  waiting for may have left already)
+          if (!sync_wait_ge_or_fail(cntT + k, WU, flagp)) goto update_done;   // column k final in LDS
+          STAMP(3);
+          // U1: column k+1 and the diagonal tile D_{k+2} first
+          const int sa = slo(c), sb = slo(c + 1), offc = off(c);
+          const double* pj = buf + (16 * c + lc) * PP + lq;         // L_{k+1,k} rows: the A operand
           for (int s = sa; s < sb; ++s) {
-            const int ti = k + (s * WU + wave - offk);
-            if (ti == k) continue;
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
-            const double* pa = buf + (16 * ti + lc) * PP + lq;                                     \
-            const double* pw = Wk + lc * PP + lq;                                                  \
-            TILE_MFMA4_SET(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pw[0], pw[4], pw[8], pw[12]);
-            SCAML_DISPATCH(s)
-#undef SCAML_BODY
-          }
-          MFMA_DRAIN();
-          STAMP_K(k, 2);
-          // final tiles: back to the panel for everyone's operand reads
-          for (int s = sa; s < sb; ++s) {
-            const int ti = k + (s * WU + wave - offk);
-            if (ti == k) continue;
-            double e[4];
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e[0], e[1], e[2], e[3]);
-            SCAML_DISPATCH(s)
-#undef SCAML_BODY
-            double* prow = buf + (16 * ti + lq) * PP + lc;
-            prow[0] = e[0]; prow[4 * PP] = e[1]; prow[8 * PP] = e[2]; prow[12 * PP] = e[3];
-          }
-          STAMP_K(k, 3);
-          sync_arrive(cntT + k, lane);
-          STAMP_K(k, 4);
-          // running right-hand side: y_i -= L_ik v_k, as an MFMA product with v_k broadcast over the
-          // columns (every column of the result is L_ik v_k); each row of y has one owner per column k.
-          // (done while the slower waves finish their T)
-          for (int s = sa; s < sb; ++s) {
-            const int ti = k + (s * WU + wave - offk);
-            if (ti == k) continue;
-            const double* pa = buf + (16 * ti + lc) * PP + lq;
-            const double* pv = vv + 16 * k + lq;
-            d4_t lv = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int m = 0; m < 4; ++m) lv = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * m], pv[4 * m], lv, 0, 0, 0);
-            if (lc < 4) {
-              const double part = lc == 0 ? lv[0] : (lc == 1 ? lv[1] : (lc == 2 ? lv[2] : lv[3]));
-              ytil[16 * ti + lq + 4 * lc] -= part;
-            }
-          }
-          STAMP_K(k, 5);
-          sync_arrive(cntY + k, lane);
-          STAMP_K(k, 6);
-          store_diag(k);
-        }
-        STAMP(4);
-        if (k + 1 == NB) { __builtin_amdgcn_s_setprio(0); store_column(k); break; }
-        sync_wait_ge(cntT + k, WU);   // column k final in LDS (and everyone is done reading column k-1)
-        STAMP_K(k, 7);
-        STAMP(5);
-        {
-          // U1: column k+1 and the diagonal tile D_{k+2} first: rank-16 update, then parked (raw) in LDS
-          const int sa = slo(k + 1), sb = slo(k + 2), offk1 = off(k + 1);
-          const double* pb = buf + (16 * (k + 1) + lc) * PP + lq;
-          for (int s = sa; s < sb; ++s) {
-            const int ti = k + 1 + (s * WU + wave - offk1);
-            if (ti == k + 1) continue;   // D_{k+1} left during U1(k-1)
-            const double* pa = buf + (16 * ti + lc) * PP + lq;
+            const int ti = c + (s * WU + wave - offc);
+            if (ti == c) continue;   // D_{k+1} left during U1(k-1)
+            const double* pi = buf + (16 * ti + lc) * PP + lq;      // L_{ti,k} rows: the B operand
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) \
-            TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]);
+            TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pj[0], pj[4], pj[8], pj[12], pi[0], pi[4], pi[8], pi[12]);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
           }
@@ -634,36 +589,70 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_BODY
           }
           MFMA_DRAIN();
-          STAMP_K(k, 8);
+          if (k + 2 < NB) park_tile(offc + 1, CR + (k & 1) * 256);   // R_{k+2} = tile (k+2, k+1), raw
+          if (own_d) park_tile(td, DG + (k & 1) * 256);
+          sync_arrive(cntS + k, lane);
+          STAMP_AT(k);
+          STAMP(4);
+        }
+        // ---- F(c): column c becomes final
+        {
+          int fw;
+          while ((fw = sync_peek(flagW + c)) == 0) __builtin_amdgcn_s_sleep(1);
+          STAMP(5);
+          if (fw == 2) break;
+          const double* Wc = WAll + c * 16 * PP;
+          const int sa = slo(c), sb = slo(c + 1), offc = off(c);
+          if (sa < sb) {
+            // forward substitution rides along: v_c = W_c y_c, formed (redundantly, identical values) by
+            // every wave that holds a tile of column c; y_c is complete once column c-1 has been folded
+            if (c >= 1 && !sync_wait_ge_or_fail(cntY + c - 1, WU, flagp)) goto update_done;
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[lc * PP + 4 * lq + q], ytil[16 * c + 4 * lq + q], v);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lq == 0) vv[16 * c + lc] = v;
+            // everyone must be done reading column c-2 (operands of U2(c-2)) before its buffer is reused
+            if (c >= 2 && !sync_wait_ge_or_fail(cntU + c - 2, WU, flagp)) goto update_done;
+          }
+          const double* pw = Wc + lc * PP + lq;
           for (int s = sa; s < sb; ++s) {
-            const int ti = k + 1 + (s * WU + wave - offk1);
-            if (ti == k + 1) continue;
-            double e0, e1, e2, e3;
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
+            const int ti = c + (s * WU + wave - offc);
+            if (ti == c) continue;
+            d4_t t;
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
+            TILE_TRSM_TO_V(r0, r1, r2, r3, r4, r5, r6, r7, pw[0], pw[4], pw[8], pw[12], t);        \
+            TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, t[0], t[1], t[2], t[3]);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
-            double* dst = nbuf + (16 * ti + lq) * PP + lc;
-            dst[0] = e0; dst[4 * PP] = e1; dst[8 * PP] = e2; dst[12 * PP] = e3;
-            if (ti == k + 2) {   // R_{k+2}: a second copy where T(k+1) will not overwrite it
-              double* cr = CR + (k & 1) * 16 * PP + lq * PP + lc;
-              cr[0] = e0; cr[4 * PP] = e1; cr[8 * PP] = e2; cr[12 * PP] = e3;
-            }
+            // lane (lc, lq) register g holds L[16 ti + lc][16 c + lq + 4 g]
+            double* prow = cbuf + (16 * ti + lc) * PP + lq;
+            prow[0] = t[0]; prow[4] = t[1]; prow[8] = t[2]; prow[12] = t[3];
           }
-          if (own_d) park_tile(td, DG + (k & 1) * 16 * PP);
+          sync_arrive(cntT + c, lane);
+          // running right-hand side: y_i -= L_ic v_c -- a row dot product per lane, summed over the
+          // four lane groups; each row of y has one owner per column
+          for (int s = sa; s < sb; ++s) {
+            const int ti = c + (s * WU + wave - offc);
+            if (ti == c) continue;
+            const double* prow = cbuf + (16 * ti + lc) * PP + lq;
+            const double* pv = vv + 16 * c + lq;
+            double sdot = prow[0] * pv[0];
+            sdot = __builtin_fma(prow[4], pv[4], sdot);
+            sdot = __builtin_fma(prow[8], pv[8], sdot);
+            sdot = __builtin_fma(prow[12], pv[12], sdot);
+            sdot += __shfl_xor(sdot, 16);
+            sdot += __shfl_xor(sdot, 32);
+            if (lq == 0) ytil[16 * ti + lc] -= sdot;
+          }
+          sync_arrive(cntY + c, lane);
+          store_diag(c);
+          STAMP(6);
         }
-        STAMP_K(k, 9);
-        sync_arrive(cntS + k, lane);
-        __builtin_amdgcn_s_setprio(0);
-        STAMP_K(k, 10);
-        STAMP_AT(k);
-        // (issuing these stores after the bulk update instead measured 4 % slower in the barrier version:
-        //  they then compete with the MFMA stream for issue slots; interleaved A/B, tools/dev_ab.py)
-        store_column(k);
-        STAMP_K(k, 11);
-        STAMP(6);
-        {
-          // U2: the bulk of the trailing update: every slot from slo(k+2) on, entered through one switch
-          // and then falling through slot after slot (the parked D_{k+2} is skipped)
+        if (k >= 0) {
+          // U2: the bulk of the trailing update with panel k: every slot from slo(k+2) on, entered through
+          // one switch and then falling through slot after slot (the parked D_{k+2} is skipped)
           const int s0 = slo(k + 2);
           int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
 #define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
@@ -672,9 +661,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
               while (uj < NB && ur >= NB - uj) { ur -= NB - uj; ++uj; }                            \
               if (uj < NB) {                                                                       \
                 if (ur != 0 || uj != k + 2) {                                                      \
-                  const double* pa = buf + (16 * (uj + ur) + lc) * PP + lq;                        \
-                  const double* pb = buf + (16 * uj + lc) * PP + lq;                               \
-                  TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pa[0], pa[4], pa[8], pa[12], pb[0], pb[4], pb[8], pb[12]); \
+                  const double* pj = buf + (16 * uj + lc) * PP + lq;                               \
+                  const double* pi = buf + (16 * (uj + ur) + lc) * PP + lq;                        \
+                  TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pj[0], pj[4], pj[8], pj[12], pi[0], pi[4], pi[8], pi[12]); \
                 }                                                                                  \
                 ur += WU;                                                                          \
               }                                                                                    \
@@ -682,10 +671,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           switch (s0) { SCAML_TILE_LIST(SCAML_U2_) default: break; }
 #undef SCAML_U2_
           MFMA_DRAIN();
+          sync_arrive(cntU + k, lane);
+          STAMP(7);
         }
-        STAMP_K(k, 12);
-        STAMP(7);
+        store_column(c);
+        STAMP(8);
       }
+    update_done:;
     }
   }
   __syncthreads();
@@ -693,6 +685,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 
   // ---- scalars: quad, logdet (panel wave), then alpha by blocked back-substitution
   STAMP(15);
+#if defined(SCAML_STAMPS_PER_PANEL) && !defined(SCAML_STAMPS_ONE_PANEL)
+  if (!is_panel) { st_acc[14] = __builtin_amdgcn_s_memtime() - st_prev; }   // loop left (slot 14 = U1(14) never runs... overwritten on purpose)
+#endif
   if (!fail) {
     if (is_panel) {
       double q = 0.0, ld = 0.0;
@@ -739,9 +734,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (is_panel) {
           if (lq == 0) dl[16 * k + lc] = ak;   // dl is free by now: alpha is collected there
         } else {
-          // alpha_k[lq + 4 g] for the four rows of this lane's tile elements
-          const double a0 = __shfl(ak, lq), a1 = __shfl(ak, lq + 4), a2 = __shfl(ak, lq + 8), a3 = __shfl(ak, lq + 12);
-          // tiles (k, j), j < k, held by this wave
+          // tiles (k, j), j < k, held by this wave: register g of lane (lc, lq) is L_kj[lc][lq + 4 g], so the
+          // lane scales by its own alpha_k[lc] and the column sums run over the 16 lanes of a DPP row
           const int* rl = rowlist + (wave * NB + k) * 8;
           const int cnt = rl[0];
           for (int i = 0; i < cnt; ++i) {
@@ -750,12 +744,16 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
-            double part = e0 * a0;
-            part = __builtin_fma(e1, a1, part);
-            part = __builtin_fma(e2, a2, part);
-            part = __builtin_fma(e3, a3, part);
-            // four lane groups add into the same w_j entry: LDS fp64 atomic, no return value
-            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ww + 16 * j + lc), -part);
+            const double p0 = row_sum_to_lane15(e0 * ak), p1 = row_sum_to_lane15(e1 * ak);
+            const double p2 = row_sum_to_lane15(e2 * ak), p3 = row_sum_to_lane15(e3 * ak);
+            if (lc == 15) {
+              // several tiles of block row k (on different waves) add into the same w_j: LDS fp64 atomics
+              __attribute__((address_space(3))) double* wj = (__attribute__((address_space(3))) double*)(ww + 16 * j + lq);
+              __builtin_amdgcn_ds_atomic_fadd_f64(wj, -p0);
+              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 4, -p1);
+              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 8, -p2);
+              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 12, -p3);
+            }
           }
         }
         STAMP(13);
@@ -768,6 +766,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     }
   }
   STAMP(10);
+#if defined(SCAML_STAMPS_PER_PANEL) && !defined(SCAML_STAMPS_ONE_PANEL)
+  if (!is_panel) { st_acc[15] = __builtin_amdgcn_s_memtime() - st_prev; }   // end of the attempt
+#endif
   STAMP_FLUSH(task);
   return fail;
 }
