@@ -108,11 +108,19 @@ __device__ __forceinline__ bool sync_wait_ge_or_fail(const int* p, int target, c
   }
   return true;
 }
+// Signalling side.  The LDS unit executes the DS instructions of one wave in issue order, so a counter
+// update issued after the data writes is performed after them: no s_waitcnt is needed in front of it
+// (a release fence would put one there and stall the wave for the full LDS write latency at every
+// hand-off).  The asm statements only pin the compiler's ordering.
 __device__ __forceinline__ void sync_arrive(int* p, int lane) {
-  if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void sync_publish(int* p, int value, int lane) {
-  if (lane == 0) __hip_atomic_store((lds_int_t*)p, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_store((lds_int_t*)p, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
 }
 
 // ---- panel wave: Cholesky of one 16x16 diagonal block and its inverse ----
@@ -260,7 +268,35 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, d
                : "=&v"(out)                                                                        \
                : "v"(w0), "v"(w1), "v"(w2), "v"(w3))
 
+// the same without the trailing wait: several tiles are issued back to back, one MFMA_DRAIN after the last
+#define TILE_TRSM_ISSUE(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, out)                       \
+  asm volatile("s_nop 1\n\t"                                                                     \
+               "v_mfma_f64_16x16x4_f64 %0, %1, a[" #r0 ":" #r1 "], 0\n\t"                         \
+               "v_mfma_f64_16x16x4_f64 %0, %2, a[" #r2 ":" #r3 "], %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, %3, a[" #r4 ":" #r5 "], %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, %4, a[" #r6 ":" #r7 "], %0"                             \
+               : "=&v"(out)                                                                        \
+               : "v"(w0), "v"(w1), "v"(w2), "v"(w3))
+
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
+
+// x summed over the four lane groups lq (lanes l, l^16, l^32, l^48), result in every lane: gfx950's
+// v_permlane{32,16}_swap exchange half-waves / odd-even rows in one VALU op per dword (no LDS crossbar)
+__device__ __forceinline__ double sum_lane_groups(double x) {
+  {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  {
+    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  }
+  return x;
+}
 
 // sum over the 16 lanes of a DPP row (same lq): the total lands in lane lc == 15
 template <int CTRL>
@@ -294,6 +330,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   constexpr int NP = NB * 16;                 // padded matrix order
   constexpr int NT = NB * (NB + 1) / 2;       // lower-triangular tiles
   constexpr int SLOTS = (NT + WU - 1) / WU;   // tiles per update wave
+  constexpr int MAXC = (NB + WU - 1) / WU;    // ... of which at most this many in one column
   constexpr int PANEL = NP * PP;              // doubles per LDS panel buffer
   constexpr int NTHREADS = (WU + 1) * 64;
   static_assert(SLOTS <= 20, "tile_regs.inc provides 20 accumulator tiles");
@@ -309,21 +346,25 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* CR = DG + 2 * 256;
   double* LT = CR + 2 * 256;
   constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
-  const int regionA = (p.D * NP > REGION_A) ? p.D * NP : REGION_A;
+  // (during the build: xsT, then up to 15 tile images written by the panel wave, see PANEL_BUILDS)
+  const int buildA = p.D * NP + 2 + 15 * 256;
+  const int regionA = (buildA > REGION_A) ? buildA : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
   double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
   double* dl = ww + NP;           // [NP] diag(L)
-  double* trash = dl + NP;        // [64] per-lane dump slot of the panel wave
+  double* trash = dl + NP;        // [64] per-lane dump slot of the panel wave (+ [WU][16] alpha_k scratch, see akscr)
   double* exptab = trash + 64;    // [64] 2^(j/64) for exp_neg
   int* rowlist = (int*)(exptab + 64);  // [WU][NB][8]: count, then up to 7 packed (slot << 8 | column) per block row
-  double* invl = exptab + 64 + WU * NB * 4;  // [D]  1 / lengthscale
+  double* akscr = exptab + 64 + WU * NB * 4;  // [WU][16] alpha_k by wave (back-substitution)
+  double* invl = akscr + WU * 16;  // [D]  1 / lengthscale
   int* flagp = (int*)(invl + p.D + (p.D & 1));  // [2] fail index
   int* flagW = flagp + 2;        // [NB] 1: W_k, v_k, L_kk published by the panel wave; 2: failed pivot
   int* cntT = flagW + NB;        // [NB] update waves done with T(k): column k final in LDS
   int* cntS = cntT + NB;         // [NB] update waves done with U1(k): column k+1 and D_{k+2} parked
   int* cntY = cntS + NB;         // [NB] update waves done folding column k into the right-hand side
   int* cntU = cntY + NB;         // [NB] update waves done with U2(k): nobody reads column k any more
+  int* cntB = cntU + NB;         // [NB] back-substitution: tiles (i, k), i > k, already folded into w_k
 
   const int task = blockIdx.x;
   const int tid = threadIdx.x;
@@ -360,7 +401,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();  // previous attempt done with region A
     if (!from_matrix && tid < D) invl[tid] = 1.0 / th[tid];
     if (tid == 0) flagp[0] = 0;
-    if (tid < 5 * NB) flagW[tid] = 0;
+    if (tid < 6 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);
     if (!is_panel && lane == 0) {
       // which off-diagonal tiles of each block row this wave holds (for the back-substitution)
@@ -388,49 +429,91 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();
     STAMP(0);
 
-    // ---- kernel matrix straight into the accumulator tiles (update waves)
+    // ---- kernel matrix straight into the accumulator tiles
+    // One 16x16 tile (block row kj + kr, block column kj), the four values of this lane (transposed tile:
+    // the lane owns a row piece).
+    auto build_tile = [&](int kj, int kr, double (&kt)[4]) {
+      const int row = 16 * (kj + kr) + lc;
+      const int col0 = 16 * kj + lq;
+      if (from_matrix) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = col0 + 4 * g;
+          double kv = 0.0;
+          if (row < n && col < n) kv = row >= col ? Ag[(size_t)row * N + col] : Ag[(size_t)col * N + row];
+          if (row == col) kv += diag_add;
+          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
+          kt[g] = kv;
+        }
+      } else {
+        double d2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+        for (int d = 0; d < D; ++d) {
+          const double* xr = xsT + d * NP;
+          const double xc = xr[row];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            double df = xr[col0 + 4 * g] - xc;
+            d2[g] = __builtin_fma(df, df, d2[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = col0 + 4 * g;
+          double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+          if (row == col) kv += diag_add;
+          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
+          kt[g] = kv;
+        }
+      }
+    };
+    // The build is VALU work, two waves per SIMD -- except on the SIMD of the (otherwise idle) panel
+    // wave.  With 7 update waves the panel wave therefore builds the tiles of slots >= KSLOT of the six
+    // update waves that do not share its SIMD (15 of the 136 tiles) into LDS images, which their owners
+    // pick up after the barrier: every SIMD then evaluates 34 tiles.
+    constexpr bool PANEL_BUILDS = (WU == 7 && NB == 16);
+    constexpr int KSLOT = 17, KMATE = 3;   // wave KMATE shares the panel wave's SIMD (waves go round-robin)
+    double* KT = lds + ((D * NP + 1) & ~1);   // [15][256] register images, behind xsT
     if (!is_panel) {
       int kj = 0, kr = wave;  // column / row-in-column of the current slot's tile
 #define SCAML_KBUILD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
-      if (S < SLOTS) {                                                                             \
+      if (S < SLOTS && !(PANEL_BUILDS && S >= KSLOT && wave != KMATE)) {                           \
         while (kj < NB && kr >= NB - kj) { kr -= NB - kj; ++kj; }                                  \
         if (kj < NB) {                                                                             \
-          const int row = 16 * (kj + kr) + lc;   /* transposed tile: the lane owns a row piece */  \
-          const int col0 = 16 * kj + lq;                                                           \
           double kt[4];                                                                            \
-          if (from_matrix) {                                                                       \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
-              const int col = col0 + 4 * g;                                                        \
-              double kv = 0.0;                                                                     \
-              if (row < n && col < n) kv = row >= col ? Ag[(size_t)row * N + col] : Ag[(size_t)col * N + row]; \
-              if (row == col) kv += diag_add;                                                      \
-              if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                               \
-              kt[g] = kv;                                                                          \
-            }                                                                                      \
-          } else {                                                                                 \
-            double d2[4] = {0.0, 0.0, 0.0, 0.0};                                                   \
-            _Pragma("unroll 2") for (int d = 0; d < D; ++d) {                                      \
-              const double* xr = xsT + d * NP;                                                     \
-              const double xc = xr[row];                                                           \
-              _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                      \
-                double df = xr[col0 + 4 * g] - xc;                                                 \
-                d2[g] = __builtin_fma(df, df, d2[g]);                                              \
-              }                                                                                    \
-            }                                                                                      \
-            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                        \
-              const int col = col0 + 4 * g;                                                        \
-              double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);                            \
-              if (row == col) kv += diag_add;                                                      \
-              if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;                               \
-              kt[g] = kv;                                                                          \
-            }                                                                                      \
-          }                                                                                        \
+          build_tile(kj, kr, kt);                                                                  \
           TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                    \
           kr += WU;                                                                                \
         }                                                                                          \
       }
       SCAML_TILE_LIST(SCAML_KBUILD_)
 #undef SCAML_KBUILD_
+    } else if (PANEL_BUILDS) {
+      for (int idx = 0; idx < 6 * (SLOTS - KSLOT); ++idx) {
+        const int s = KSLOT + idx / 6, w6 = idx % 6, w = w6 + (w6 >= KMATE);
+        const int t = s * WU + w;
+        if (t >= NT) continue;
+        int kj = 0, kr = t;
+        while (kr >= NB - kj) { kr -= NB - kj; ++kj; }
+        double kt[4];
+        build_tile(kj, kr, kt);
+        double* img = KT + idx * 256 + lane;
+        img[0] = kt[0]; img[64] = kt[1]; img[128] = kt[2]; img[192] = kt[3];
+      }
+    }
+#ifdef SCAML_STAMPS
+    if (is_panel) { STAMP(8); } else { STAMP(9); }   // own share of the build done (diagnostic build only)
+#endif
+    __syncthreads();  // xsT dead from here
+    if (PANEL_BUILDS && !is_panel && wave != KMATE) {
+      const int w6 = wave - (wave > KMATE);
+#define SCAML_KLOAD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
+      if (S >= KSLOT && S < SLOTS && S * WU + wave < NT) {                                         \
+        const double* img = KT + ((S - KSLOT) * 6 + w6) * 256 + lane;                              \
+        TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, img[0], img[64], img[128], img[192]);             \
+      }
+      SCAML_TILE_LIST(SCAML_KLOAD_)
+#undef SCAML_KLOAD_
     }
     __syncthreads();  // xsT dead from here: region A becomes PT / WAll
     STAMP(1);
@@ -466,11 +549,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       __builtin_amdgcn_s_setprio(3);
       for (int j = 0; j < NB; ++j) {
         double* Wj = WAll + j * 16 * PP;
-        STAMP_K(j, 0);
         // D_j (updates of panels <= j-2 applied) and the raw tile R_j = A[j][j-1] were parked by their
         // owners during U1(j-2): one whole step of slack, the chain does not wait in steady state
         if (j >= 2) sync_wait_ge(cntS + j - 2, WU);
-        STAMP_K(j, 1);
         STAMP(3);
         d4_t a;
         {
@@ -490,11 +571,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           for (int m = 0; m < 4; ++m) a = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[m], tm[m], a, 0, 0, 1);
         }
         STAMP(4);
-        STAMP_K(j, 2);
         double* LTj = LT + (j & 1) * 16 * PP;
         const int bad = potf2_inv_block(a, LTj, Wj, trash, j, lane);
         STAMP(5);
-        STAMP_K(j, 3);
         if (lq == 0) dl[16 * j + lc] = LTj[lc * PP + lc];   // diag(L) for logdet
         if (bad) {
           if (lane == 0) flagp[0] = bad;
@@ -502,7 +581,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           break;
         }
         sync_publish(flagW + j, 1, lane);
-        STAMP_K(j, 6);
         STAMP_AT(j);
         STAMP(9);
       }
@@ -564,7 +642,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (k >= 0) {
           // (every wait below gives up when the panel wave has reported a failed pivot: the waves it is
           //  waiting for may have left already)
+          STAMP_K(k, 0);
           if (!sync_wait_ge_or_fail(cntT + k, WU, flagp)) goto update_done;   // column k final in LDS
+          STAMP_K(k, 1);
           STAMP(3);
           // U1: column k+1 and the diagonal tile D_{k+2} first
           const int sa = slo(c), sb = slo(c + 1), offc = off(c);
@@ -589,9 +669,11 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_BODY
           }
           MFMA_DRAIN();
+          STAMP_K(k, 2);
           if (k + 2 < NB) park_tile(offc + 1, CR + (k & 1) * 256);   // R_{k+2} = tile (k+2, k+1), raw
           if (own_d) park_tile(td, DG + (k & 1) * 256);
           sync_arrive(cntS + k, lane);
+          STAMP_K(k, 3);
           STAMP_AT(k);
           STAMP(4);
         }
@@ -599,55 +681,90 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         {
           int fw;
           while ((fw = sync_peek(flagW + c)) == 0) __builtin_amdgcn_s_sleep(1);
+          STAMP_K(k, 4);
           STAMP(5);
           if (fw == 2) break;
           const double* Wc = WAll + c * 16 * PP;
           const int sa = slo(c), sb = slo(c + 1), offc = off(c);
+          // everyone must be done reading column c-2 (operands of U2(c-2)) before its buffer is reused
+          if (sa < sb && c >= 2 && !sync_wait_ge_or_fail(cntU + c - 2, WU, flagp)) goto update_done;
+          STAMP_K(k, 6);
+          const double* pw = Wc + lc * PP + lq;
+          const double w0 = pw[0], w1 = pw[4], w2 = pw[8], w3 = pw[12];
+          d4_t t[MAXC];
+#pragma unroll
+          for (int u = 0; u < MAXC; ++u) {
+            const int s = sa + u;
+            if (s < sb && c + (s * WU + wave - offc) != c) {
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_TRSM_ISSUE(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, t[u]);
+              SCAML_DISPATCH(s)
+#undef SCAML_BODY
+            }
+          }
           if (sa < sb) {
-            // forward substitution rides along: v_c = W_c y_c, formed (redundantly, identical values) by
-            // every wave that holds a tile of column c; y_c is complete once column c-1 has been folded
+            // forward substitution rides along (in the shadow of the MFMAs just issued): v_c = W_c y_c,
+            // formed (redundantly, identical values) by every wave that holds a tile of column c; y_c is
+            // complete once column c-1 has been folded
             if (c >= 1 && !sync_wait_ge_or_fail(cntY + c - 1, WU, flagp)) goto update_done;
             double v = 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[lc * PP + 4 * lq + q], ytil[16 * c + 4 * lq + q], v);
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
+            v = sum_lane_groups(v);
             if (lq == 0) vv[16 * c + lc] = v;
-            // everyone must be done reading column c-2 (operands of U2(c-2)) before its buffer is reused
-            if (c >= 2 && !sync_wait_ge_or_fail(cntU + c - 2, WU, flagp)) goto update_done;
+            STAMP_K(k, 5);
           }
-          const double* pw = Wc + lc * PP + lq;
-          for (int s = sa; s < sb; ++s) {
+          MFMA_DRAIN();
+          STAMP_K(k, 7);
+#pragma unroll
+          for (int u = 0; u < MAXC; ++u) {
+            const int s = sa + u;
             const int ti = c + (s * WU + wave - offc);
-            if (ti == c) continue;
-            d4_t t;
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7)                                                 \
-            TILE_TRSM_TO_V(r0, r1, r2, r3, r4, r5, r6, r7, pw[0], pw[4], pw[8], pw[12], t);        \
-            TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, t[0], t[1], t[2], t[3]);
-            SCAML_DISPATCH(s)
-#undef SCAML_BODY
-            // lane (lc, lq) register g holds L[16 ti + lc][16 c + lq + 4 g]
-            double* prow = cbuf + (16 * ti + lc) * PP + lq;
-            prow[0] = t[0]; prow[4] = t[1]; prow[8] = t[2]; prow[12] = t[3];
+            if (s < sb && ti != c) {
+              asm volatile("" : "+v"(t[u]));   // the values exist only after the drain
+              // lane (lc, lq) register g holds L[16 ti + lc][16 c + lq + 4 g]
+              double* prow = cbuf + (16 * ti + lc) * PP + lq;
+              prow[0] = t[u][0]; prow[4] = t[u][1]; prow[8] = t[u][2]; prow[12] = t[u][3];
+            }
           }
           sync_arrive(cntT + c, lane);
-          // running right-hand side: y_i -= L_ic v_c -- a row dot product per lane, summed over the
-          // four lane groups; each row of y has one owner per column
-          for (int s = sa; s < sb; ++s) {
-            const int ti = c + (s * WU + wave - offc);
-            if (ti == c) continue;
-            const double* prow = cbuf + (16 * ti + lc) * PP + lq;
+          STAMP_K(k, 8);
+          // running right-hand side: y_i -= L_ic v_c -- a row dot product per lane; the four lane groups
+          // add their parts with LDS fp64 atomics (each row of y has one owner tile per column)
+          {
             const double* pv = vv + 16 * c + lq;
-            double sdot = prow[0] * pv[0];
-            sdot = __builtin_fma(prow[4], pv[4], sdot);
-            sdot = __builtin_fma(prow[8], pv[8], sdot);
-            sdot = __builtin_fma(prow[12], pv[12], sdot);
-            sdot += __shfl_xor(sdot, 16);
-            sdot += __shfl_xor(sdot, 32);
-            if (lq == 0) ytil[16 * ti + lc] -= sdot;
+            const double v0 = pv[0], v1 = pv[4], v2 = pv[8], v3 = pv[12];
+#pragma unroll
+            for (int u = 0; u < MAXC; ++u) {
+              const int s = sa + u;
+              const int ti = c + (s * WU + wave - offc);
+              if (s < sb && ti != c) {
+                double sdot = t[u][0] * v0;
+                sdot = __builtin_fma(t[u][1], v1, sdot);
+                sdot = __builtin_fma(t[u][2], v2, sdot);
+                sdot = __builtin_fma(t[u][3], v3, sdot);
+                __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ytil + 16 * ti + lc), -sdot);
+              }
+            }
+          }
+          // The finished tiles go back into their registers UN-transposed (read back from the panel:
+          // lane (lc, lq) register g = L[16 ti + lq + 4 g][16 c + lc]): nothing updates them any more, and
+          // the back-substitution at the end contracts over rows, which this layout keeps inside a lane.
+#pragma unroll
+          for (int u = 0; u < MAXC; ++u) {
+            const int s = sa + u;
+            const int ti = c + (s * WU + wave - offc);
+            if (s < sb && ti != c) {
+              const double* prow = cbuf + (16 * ti + lq) * PP + lc;
+              const double e0 = prow[0], e1 = prow[4 * PP], e2 = prow[8 * PP], e3 = prow[12 * PP];
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
+              SCAML_DISPATCH(s)
+#undef SCAML_BODY
+            }
           }
           sync_arrive(cntY + c, lane);
+          STAMP_K(k, 9);
           store_diag(c);
+          STAMP_K(k, 10);
           STAMP(6);
         }
         if (k >= 0) {
@@ -672,9 +789,11 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_U2_
           MFMA_DRAIN();
           sync_arrive(cntU + k, lane);
+          STAMP_K(k, 11);
           STAMP(7);
         }
         store_column(c);
+        STAMP_K(k, 12);
         STAMP(8);
       }
     update_done:;
@@ -716,53 +835,52 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       for (int e = tid; e < nbn * 256; e += NTHREADS) Wg[e] = WAll[(e >> 4) * PP + (e & 15)];
     }
     if (p.alpha) {
-      // alpha = L^-T v by blocks from the bottom.  Per block k every wave forms alpha_k = W_k^T w_k
-      // itself (a 16x16 mat-vec out of LDS: four terms per lane group, then two cross-group adds),
-      // the update waves then fold alpha_k into w_j for the tiles (k, j) they hold in registers; one
-      // barrier per block.
+      // alpha = L^-T v by blocks from the bottom, as a dataflow without barriers.  Block k: once every
+      // tile below it in column k has been folded into w_k (cntB[k]), every wave forms alpha_k = W_k^T w_k
+      // itself (a 16x16 mat-vec out of LDS: four terms per lane group, then two cross-group adds); the
+      // update waves then fold alpha_k into w_j for the tiles (k, j) they hold in registers, the tile
+      // next to the diagonal first (w_{k-1} is needed first).
       for (int r = tid; r < NP; r += NTHREADS) ww[r] = vv[r];
       __syncthreads();
       STAMP(11);
       for (int k = NB - 1; k >= 0; --k) {
+        sync_wait_ge(cntB + k, NB - 1 - k);
         const double* Wk = WAll + k * 16 * PP;
         double ak = 0.0;
 #pragma unroll
         for (int c = 0; c < 4; ++c) ak = __builtin_fma(Wk[(4 * lq + c) * PP + lc], ww[16 * k + 4 * lq + c], ak);
-        ak += __shfl_xor(ak, 16);
-        ak += __shfl_xor(ak, 32);   // every lane (lc, *) now holds alpha_k[lc]
+        ak = sum_lane_groups(ak);   // every lane (lc, *) now holds alpha_k[lc]
         STAMP(12);
         if (is_panel) {
           if (lq == 0) dl[16 * k + lc] = ak;   // dl is free by now: alpha is collected there
         } else {
-          // tiles (k, j), j < k, held by this wave: register g of lane (lc, lq) is L_kj[lc][lq + 4 g], so the
-          // lane scales by its own alpha_k[lc] and the column sums run over the 16 lanes of a DPP row
+          // tiles (k, j), j < k, held by this wave: register g of lane (lc, lq) is L_kj[lq + 4 g][lc], so the
+          // lane needs alpha_k[lq + 4 g] (through a 16-double LDS scratch of the wave) and adds its four
+          // terms; the four lane groups meet in w_j[lc] through LDS fp64 atomics
+          double* akw = akscr + wave * 16;
+          if (lq == 0) akw[lc] = ak;
+          const double a0 = akw[lq], a1 = akw[lq + 4], a2 = akw[lq + 8], a3 = akw[lq + 12];
           const int* rl = rowlist + (wave * NB + k) * 8;
           const int cnt = rl[0];
-          for (int i = 0; i < cnt; ++i) {
+          for (int i = cnt - 1; i >= 0; --i) {
             const int sj = rl[1 + i], s = sj >> 8, j = sj & 0xff;
             double e0, e1, e2, e3;
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_GET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
             SCAML_DISPATCH(s)
 #undef SCAML_BODY
-            const double p0 = row_sum_to_lane15(e0 * ak), p1 = row_sum_to_lane15(e1 * ak);
-            const double p2 = row_sum_to_lane15(e2 * ak), p3 = row_sum_to_lane15(e3 * ak);
-            if (lc == 15) {
-              // several tiles of block row k (on different waves) add into the same w_j: LDS fp64 atomics
-              __attribute__((address_space(3))) double* wj = (__attribute__((address_space(3))) double*)(ww + 16 * j + lq);
-              __builtin_amdgcn_ds_atomic_fadd_f64(wj, -p0);
-              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 4, -p1);
-              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 8, -p2);
-              __builtin_amdgcn_ds_atomic_fadd_f64(wj + 12, -p3);
-            }
+            double part = e0 * a0;
+            part = __builtin_fma(e1, a1, part);
+            part = __builtin_fma(e2, a2, part);
+            part = __builtin_fma(e3, a3, part);
+            __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ww + 16 * j + lc), -part);
+            sync_arrive(cntB + j, lane);
           }
         }
         STAMP(13);
-        __syncthreads();
-        STAMP(14);
       }
-      for (int r = tid; r < NP; r += NTHREADS) ww[r] = dl[r];
       __syncthreads();
-      for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = ww[r];
+      STAMP(14);
+      for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = dl[r];
     }
   }
   STAMP(10);

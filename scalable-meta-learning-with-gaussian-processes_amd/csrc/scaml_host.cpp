@@ -95,9 +95,10 @@ Module& module() {
 size_t fit_lds_bytes(int nb, int wu, int D) {
   const int np = nb * 16;
   size_t regionA = (size_t)2 * np * PP + (size_t)(nb + 2) * 16 * PP + 4 * 256;   // PT[2], WAll[nb], LT[2], DG[2], CR[2]
-  if ((size_t)D * np > regionA) regionA = (size_t)D * np;
-  // + vectors, trash/exp table, row lists, 1/l, fail flag + 5 nb hand-off counters (ints)
-  return (regionA + 4 * np + 128 + (size_t)wu * nb * 4 + D + (D & 1) + 2 + (5 * (size_t)nb + 1) / 2) * sizeof(double);
+  const size_t buildA = (size_t)D * np + 2 + 15 * 256;   // X/l transposed + the panel wave's tile images
+  if (buildA > regionA) regionA = buildA;
+  // + vectors, trash/exp table, row lists, 1/l, fail flag + 6 nb hand-off counters (ints)
+  return (regionA + 4 * np + 128 + (size_t)wu * nb * 4 + (size_t)wu * 16 + D + (D & 1) + 2 + 3 * (size_t)nb) * sizeof(double);
 }
 
 }  // namespace

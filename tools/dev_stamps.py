@@ -10,7 +10,8 @@ if ONE:
 PER_PANEL = "--per-panel" in sys.argv
 if PER_PANEL:
     sys.argv.remove("--per-panel")
-lib = ctypes.CDLL(os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd", "lib", ("libscaml_hip_onepanel%s.so" % ONE[0][len("--one-panel"):]) if ONE else ("libscaml_hip_perpanel.so" if PER_PANEL else "libscaml_hip_stamps.so")))
+_name = ("libscaml_hip_onepanel%s.so" % ONE[0][len("--one-panel"):]) if ONE else ("libscaml_hip_perpanel.so" if PER_PANEL else "libscaml_hip_stamps%s.so" % os.environ.get("STAMP_WAVE", "0"))
+lib = ctypes.CDLL(os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd", "lib", _name))
 vp = ctypes.c_void_p
 lib.scaml_gp_fit_fused_f64.argtypes = [vp]*5 + [ctypes.c_int]*4 + [vp]*8 + [ctypes.c_uint, vp]
 lib.scaml_debug_set_stamp_buffer.argtypes = [vp]
@@ -32,10 +33,11 @@ torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.float64)
 if ONE:
     med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0)
-    nu = ["iter start", "flagW seen", "TRSM done+drain", "final tiles in LDS", "arrived cntT", "fold done", "arrived cntY", "cntT complete", "U1 mfma+drain", "parked", "arrived cntS", "stores issued", "U2 done"]
-    npn = ["step start", "cntS[j-2] seen", "own TRSM+diag upd", "potf2 done", "cntY[j-1] seen", "v_j done", "pre-read + publish"]
+    nu = ["iter start", "cntT[k] complete", "U1 mfma+drain", "parked, arrived cntS", "flagW[k+1] seen", "cntY wait + v done", "cntU[k-1] seen", "TRSM issue+drain",
+          "tiles set, panel written, arrived cntT", "fold, arrived cntY", "diag stored", "U2 done, arrived cntU", "column stored"]
+    npn = [""] * 7
     for i in range(13):
-        print(f"{nu[i]:22s} {med[i]:10.0f} {med[i]-(med[i-1] if i else med[0]):8.0f}   | " + (f"{npn[i]:22s} {medp[i]:10.0f} {medp[i]-(medp[i-1] if i else medp[0]):8.0f}" if i < 7 else ""))
+        print(f"{nu[i]:40s} {med[i]:10.0f} {med[i]-(med[i-1] if i else med[0]):8.0f}   | " + "")
     sys.exit(0)
 if PER_PANEL:
     med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0)
@@ -44,14 +46,14 @@ if PER_PANEL:
         print(f"{k:2d} {med[k]:12.0f} {med[k]-(med[k-1] if k else 0):8.0f}   | {medp[k]:12.0f} {medp[k]-(medp[k-1] if k else 0):8.0f}")
     sys.exit(0)
 # stamp slots: 0-2 common; 3-9 differ per role; 10-15 tail
-names_u = {0: "load X,y", 1: "K-build", 2: "prologue (park tiles)", 3: "wait flagW[k]", 4: "T: trsm + stores", 5: "wait cntT[k]",
-           6: "U1: col k+1, D_k+2 + park", 7: "U2: bulk update", 15: "loop exit barrier", 11: "tail: scalars+copy+bar",
+names_u = {0: "load X,y", 9: "K-build (own tiles)", 1: "K-build: barrier + image loads", 2: "prologue (park tiles)", 3: "wait cntT[k]", 4: "U1: col k+1, D_k+2 + park", 5: "wait flagW[k+1]",
+           6: "F: v, trsm, panel write, fold", 7: "U2: bulk update", 8: "column k+1 -> HBM", 15: "loop exit barrier", 11: "tail: scalars+copy+bar",
            12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
-names_p = {0: "load X,y", 1: "(K-build: idle)", 2: "prologue", 3: "wait cntS[j-2] (D_j)", 4: "own TRSM + diag update", 5: "potf2",
-           6: "wait cntT[j-1]", 7: "fold + v_j", 8: "wait cntS[j-1] + pre-read", 9: "publish + diag store", 15: "loop exit barrier",
+names_p = {0: "load X,y", 8: "K-build (15 tile images)", 1: "K-build: barrier", 2: "prologue", 3: "wait cntS[j-2] (D_j, R_j)", 4: "own TRSM + diag update", 5: "potf2",
+           9: "dl + publish", 15: "loop exit barrier",
            11: "tail: scalars+copy+bar", 12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
 med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0); tot = med.sum(); totp = medp.sum()
-order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 11, 12, 13, 14, 10]
+order = [0, 9, 8, 1, 2, 3, 4, 5, 6, 7, 15, 11, 12, 13, 14, 10] if False else [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 11, 12, 13, 14, 10]
 print(f"{'update wave 0':30s} {'cycles':>9s} {'%':>6s}   | {'panel wave':30s} {'cycles':>9s} {'%':>6s}")
 for i in order:
     print(f"{names_u.get(i, '-'):30s} {med[i]:9.0f} {100*med[i]/tot:5.1f}%   | {names_p.get(i, '-'):30s} {medp[i]:9.0f} {100*medp[i]/totp:5.1f}%")
