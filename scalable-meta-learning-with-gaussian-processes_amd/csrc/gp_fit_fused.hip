@@ -130,22 +130,30 @@ __device__ __forceinline__ void sync_publish(int* p, int value, int lane) {
 // MFMA latency is off the pivot chain.  A second accumulator R (initially I) receives the same row
 // operations and ends as W = L_kk^-1.  Lanes outside the active group store to a per-lane trash
 // slot instead of being masked off (no exec juggling in the 16-step chain).
-// Outputs: LT[r * PP + c] = L_kk[r][c] (zero above the diagonal), Wk[c * PP + j] = W[c][j].
+// Outputs: LT[r * PP + c] = L_kk[r][c] (zero above the diagonal), Wt[j * PP + c] = W[c][j] (W TRANSPOSED:
+// both stores of step c then sit at the immediate offset c from a per-lane base that is fixed for the
+// whole block, no address arithmetic inside the chain).
 // Returns 0 or the 1-based global index of the first non-positive / out-of-range pivot.
-__device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, double* trash, int k, int lane) {
+__device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, double* trash, int k, int lane) {
   const int lc = lane & 15, lq = lane >> 4;
   d4_t R;
 #pragma unroll
   for (int g = 0; g < 4; ++g) R[g] = (lc == lq + 4 * g) ? 1.0 : 0.0;
-  // LDS element offsets relative to `LT` (the trash slot is addressed through the same base)
-  const int off_trash = (int)(trash - LT) + lane;
-  const int off_prow = lc * PP;              // + c   -> L[lc][c]
-  const int off_w = (int)(Wk - LT) + lc;     // + c*PP -> W[c][lc]
+  // per-lane store bases: step c is written by lane group c & 3 only, the other groups dump into their
+  // trash slot (trash[lane + 0..15]: 80 doubles)
+  typedef __attribute__((address_space(3))) double lds_double_t;   // 32-bit LDS pointers: 8 VGPRs in all
+  lds_double_t* baseL[4];
+  lds_double_t* baseW[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    baseL[g] = (lds_double_t*)((lq == g) ? LT + lc * PP : trash + lane);
+    baseW[g] = (lds_double_t*)((lq == g) ? Wt + lc * PP : trash + lane);
+  }
   // Pivot chain per step: rsqrt(dpiv) -> ri^2 -> next dpiv.  Everything else hangs off it: the raw
   // row values are masked and read across lanes as soon as the previous MFMA lands (before ri is
-  // known), the range check only feeds `bad`, the two MFMAs and the LDS stores trail behind.
-  bool okall = true;
-  double piv[16];
+  // known), the range check is one running minimum, the two MFMAs and the LDS stores trail behind.
+  lds_double_t* pivlog = (lds_double_t*)(trash + 80);   // [16] the pivots, looked at only after a failure
+  double dmin = __builtin_inf();
   double dpiv = readlane_f64(a[0], 0);
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
@@ -154,11 +162,11 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, d
     const bool low = (unsigned)(lane - (16 * g + c)) < (unsigned)(16 - c);  // mine && lc >= c
     const double am = low ? a[rg] : 0.0;    // raw column c (row c of the symmetric block), masked
     const double Rm = mine ? R[rg] : 0.0;
-    // non-positive, NaN (or too small for the f32-seeded rsqrt): one compare per step here, the index
-    // of the first failing step is only worked out if something failed; the garbage a failed step
-    // produces afterwards is never used
-    piv[c] = dpiv;
-    okall = okall & (dpiv >= 1e-30);
+    // non-positive, NaN (or too small for the f32-seeded rsqrt): a NaN pivot poisons every later one, so
+    // the running minimum plus the last pivot tell whether anything failed; the index of the first
+    // failing step is only worked out then.  The garbage a failed step produces is never used.
+    pivlog[c] = dpiv;
+    dmin = __builtin_fmin(dmin, dpiv);
     const double ri = rsqrt_seeded(dpiv);
     if (c < 15) {
       const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
@@ -170,20 +178,16 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wk, d
     const double wrow = Rm * ri;   // W[c][lc]
     if (c < 15) {
       a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
-#ifndef PROBE_NO_INV
       R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
-#endif
     }
-#ifndef PROBE_NO_STORE
-    LT[mine ? off_prow + c : off_trash] = lcol;
-    LT[mine ? off_w + c * PP : off_trash] = wrow;
-#endif
+    baseL[g][c] = lcol;
+    baseW[g][c] = wrow;
   }
   int bad = 0;
-  if (!okall) {
+  if (!(dmin >= 1e-30) || !(dpiv == dpiv)) {
 #pragma unroll
     for (int c = 15; c >= 0; --c)
-      if (!(piv[c] >= 1e-30)) bad = 16 * k + c + 1;
+      if (!(pivlog[c] >= 1e-30)) bad = 16 * k + c + 1;
   }
   return bad;
 }
@@ -353,8 +357,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* vv = ytil + NP;         // [NP] v = L^-1 y
   double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
   double* dl = ww + NP;           // [NP] diag(L)
-  double* trash = dl + NP;        // [64] per-lane dump slot of the panel wave (+ [WU][16] alpha_k scratch, see akscr)
-  double* exptab = trash + 64;    // [64] 2^(j/64) for exp_neg
+  double* trash = dl + NP;        // [80] per-lane dump slots of the panel wave (lane + step) + [16] pivot log
+  double* exptab = trash + 96;    // [64] 2^(j/64) for exp_neg
   int* rowlist = (int*)(exptab + 64);  // [WU][NB][8]: count, then up to 7 packed (slot << 8 | column) per block row
   double* akscr = exptab + 64 + WU * NB * 4;  // [WU][16] alpha_k by wave (back-substitution)
   double* invl = akscr + WU * 16;  // [D]  1 / lengthscale
@@ -562,11 +566,11 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (j >= 1) {
           // tm = W_{j-1} R_j^T = (L_j,j-1)^T: in the C/D layout that is L_j,j-1 in operand position,
           // so D_j -= L L^T follows without a transpose through LDS
-          const double* pw = WAll + (j - 1) * 16 * PP + lc * PP + lq;
+          const double* pw = WAll + (j - 1) * 16 * PP + lq * PP + lc;   // W[lc][lq + 4m] out of the transposed copy
           const double* pr = CR + (j & 1) * 256 + lane;   // register image of the transposed tile = R[lc][lq + 4m]
           d4_t tm = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int m = 0; m < 4; ++m) tm = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * m], pr[64 * m], tm, 0, 0, 0);
+          for (int m = 0; m < 4; ++m) tm = __builtin_amdgcn_mfma_f64_16x16x4f64(pw[4 * m * PP], pr[64 * m], tm, 0, 0, 0);
 #pragma unroll
           for (int m = 0; m < 4; ++m) a = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[m], tm[m], a, 0, 0, 1);
         }
@@ -689,8 +693,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           // everyone must be done reading column c-2 (operands of U2(c-2)) before its buffer is reused
           if (sa < sb && c >= 2 && !sync_wait_ge_or_fail(cntU + c - 2, WU, flagp)) goto update_done;
           STAMP_K(k, 6);
-          const double* pw = Wc + lc * PP + lq;
-          const double w0 = pw[0], w1 = pw[4], w2 = pw[8], w3 = pw[12];
+          const double* pw = Wc + lq * PP + lc;   // W[lc][lq + 4m] out of the transposed copy
+          const double w0 = pw[0], w1 = pw[4 * PP], w2 = pw[8 * PP], w3 = pw[12 * PP];
           d4_t t[MAXC];
 #pragma unroll
           for (int u = 0; u < MAXC; ++u) {
@@ -708,7 +712,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             if (c >= 1 && !sync_wait_ge_or_fail(cntY + c - 1, WU, flagp)) goto update_done;
             double v = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[lc * PP + 4 * lq + q], ytil[16 * c + 4 * lq + q], v);
+            for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[(4 * lq + q) * PP + lc], ytil[16 * c + 4 * lq + q], v);
             v = sum_lane_groups(v);
             if (lq == 0) vv[16 * c + lc] = v;
             STAMP_K(k, 5);
@@ -832,7 +836,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       // L^-1 K_*^T with them on the matrix cores instead of by substitution
       const int nbn = (N + 15) / 16;
       double* Wg = p.Linv_diag + (size_t)task * nbn * 256;
-      for (int e = tid; e < nbn * 256; e += NTHREADS) Wg[e] = WAll[(e >> 4) * PP + (e & 15)];
+      for (int e = tid; e < nbn * 256; e += NTHREADS)   // W[r][c] of block b = WAll[b][c][r] (kept transposed)
+        Wg[e] = WAll[(e >> 8) * 16 * PP + (e & 15) * PP + ((e >> 4) & 15)];
     }
     if (p.alpha) {
       // alpha = L^-T v by blocks from the bottom, as a dataflow without barriers.  Block k: once every
@@ -848,7 +853,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         const double* Wk = WAll + k * 16 * PP;
         double ak = 0.0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ak = __builtin_fma(Wk[(4 * lq + c) * PP + lc], ww[16 * k + 4 * lq + c], ak);
+        for (int c = 0; c < 4; ++c) ak = __builtin_fma(Wk[lc * PP + 4 * lq + c], ww[16 * k + 4 * lq + c], ak);
         ak = sum_lane_groups(ak);   // every lane (lc, *) now holds alpha_k[lc]
         STAMP(12);
         if (is_panel) {
