@@ -113,8 +113,14 @@ __device__ __forceinline__ bool sync_wait_ge_or_fail(const int* p, int target, c
 // (a release fence would put one there and stall the wave for the full LDS write latency at every
 // hand-off).  The asm statements only pin the compiler's ordering.
 __device__ __forceinline__ void sync_arrive(int* p, int lane) {
-  asm volatile("" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add((lds_int_t*)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // (written as asm: for a one-lane atomic the compiler's atomic optimiser adds a dozen instructions of
+  //  lane counting.  An LDS op the compiler does not count only makes its later s_waitcnt lgkmcnt(n)
+  //  conservative, since LDS results return in order.)
+  if (lane == 0) {
+    const unsigned addr = (unsigned)(size_t)(lds_int_t*)p;
+    const int one = 1;
+    asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(one) : "memory");
+  }
   asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void sync_publish(int* p, int value, int lane) {
@@ -461,13 +467,20 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             d2[g] = __builtin_fma(df, df, d2[g]);
           }
         }
+        // wave-uniform fast path: an off-diagonal tile entirely inside the n valid points needs neither the
+        // diagonal term nor the identity padding (saves ~10 VALU instructions per element)
+        if (kr != 0 && 16 * (kj + kr) + 16 <= n) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int col = col0 + 4 * g;
-          double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
-          if (row == col) kv += diag_add;
-          if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
-          kt[g] = kv;
+          for (int g = 0; g < 4; ++g) kt[g] = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int col = col0 + 4 * g;
+            double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+            if (row == col) kv += diag_add;
+            if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
+            kt[g] = kv;
+          }
         }
       }
     };

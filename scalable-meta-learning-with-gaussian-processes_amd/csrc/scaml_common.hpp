@@ -58,7 +58,7 @@ __device__ __forceinline__ void exp2_table_init(double* tab, int tid) {
 }
 
 __device__ __forceinline__ double exp_neg(double x, const double* tab) {
-  x = x < -746.0 ? -746.0 : x;
+  x = __builtin_fmax(x, -746.0);   // (a NaN becomes -746 -> 0, as the select did)
   const double nf = __builtin_rint(x * 92.332482616893656877);     // 64 / ln 2
   double r = __builtin_fma(nf, -0x1.62e42fee00000p-7, x);   // ln2/64, high part (21 trailing zero bits: nf * hi is exact)
   r = __builtin_fma(nf, -0x1.a39ef35793c76p-39, r);          // ln2/64, low part
@@ -71,19 +71,21 @@ __device__ __forceinline__ double exp_neg(double x, const double* tab) {
   return __builtin_ldexp(__builtin_fma(t, p, t), n >> 6);
 }
 
-// k(d2) for squared scaled distance d2 >= 0 (without the outputscale).
+// k(d2) for squared scaled distance d2 >= 0 (without the outputscale).  The clamps are v_max/v_min (which
+// drop a NaN operand); `d2 - d2` (0, or NaN for NaN / inf input) puts a NaN back, so that bad inputs
+// still fail the factorisation the way psd_safe_cholesky fails on NaN.
 template <int KIND>
 __device__ __forceinline__ double kernel_from_sqdist(double d2, const double* exp_tab) {
   if (KIND == 0) {  // RBF: exp(-d2/2)
-    return exp_neg(-0.5 * d2, exp_tab);
+    return exp_neg(-0.5 * d2, exp_tab) + (d2 - d2);
   } else {          // Matern-5/2: gpytorch clamps d2 at 1e-30 before the sqrt
-    double dd = d2 < 1e-30 ? 1e-30 : d2;
-    dd = dd > 1e30 ? 1e30 : dd;  // k == 0 out there; keeps the f32-seeded rsqrt in range
+    // (upper clamp: k == 0 out there; it keeps the f32-seeded rsqrt in range)
+    const double dd = __builtin_fmin(__builtin_fmax(d2, 1e-30), 1e30);
     const double ri = rsqrt_seeded(dd);
     const double r = sqrt_from_rinv(dd, ri);
     const double s5 = 2.2360679774997896964;
     double poly = __builtin_fma(__builtin_fma(r, 5.0 / 3.0, s5), r, 1.0);
-    return poly * exp_neg(-s5 * r, exp_tab);
+    return __builtin_fma(poly, exp_neg(-s5 * r, exp_tab), d2 - d2);
   }
 }
 
