@@ -29,8 +29,15 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
   const double* Lg = p.L + (size_t)task * N * N;
   const double* Wg = p.Linv_diag + (size_t)task * NB * 256;
   double* Og = p.Linv + (size_t)task * N * N;
-  const int strip = blockIdx.x * nwaves + wave;
-  if (strip >= NB) return;
+  // Strip s costs (NB - s)(NB - s - 1) / 2 block products: the V = gridDim.x * nwaves (virtual) waves of a task
+  // take strips in boustrophedon order (v, 2V-1-v, 2V+v, 4V-1-v, ...), which evens out their loads.
+  const int vwave = blockIdx.x * nwaves + wave, V = gridDim.x * nwaves;
+  for (int it = 0;; ++it) {
+  const int strip = (it & 1) ? (it + 1) * V - 1 - vwave : it * V + vwave;
+  if (strip >= NB) {
+    if (it * V >= NB) break;
+    continue;
+  }
   const int qc = 16 * strip + lc;  // column of the inverse owned by this lane
   // rows above the strip are zero
   for (int r = lq; r < 16 * strip && r < N; r += 4)
@@ -42,15 +49,7 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
     const int arow = 16 * kb + lc;
     const bool arow_ok = arow < n;
     const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    for (int j = strip; j < kb; ++j) {
-      const double* vb = Vs + (16 * j + lq) * 16 + lc;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int col = 16 * j + 4 * m + lq;
-        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
-      }
-    }
+    acc = subst_accumulate(acc, Lrow, arow_ok, 16 * kb + 16 <= n, n, (N & 1) == 0, Vs, strip, kb, lc, lq);
     d4_t v = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
 #pragma unroll
@@ -58,10 +57,11 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = 16 * kb + lq + 4 * g;
-      Vs[row * 16 + lc] = v[g];
+      Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
       if (row < N && qc < N) Og[(size_t)row * N + qc] = v[g];
     }
   }
+  }   // strips of this wave
 }
 
 // X = (L L^T)^-1 B for R right-hand-side columns per task: one wave per (task, strip of 16 columns).
@@ -94,33 +94,25 @@ __global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
     const int arow = 16 * kb + lc;
     const bool arow_ok = arow < n;
     const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    for (int j = 0; j < kb; ++j) {
-      const double* vb = Vs + (16 * j + lq) * 16 + lc;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int col = 16 * j + 4 * m + lq;
-        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
-      }
-    }
+    acc = subst_accumulate(acc, Lrow, arow_ok, 16 * kb + 16 <= n, n, (N & 1) == 0, Vs, 0, kb, lc, lq);
     d4_t v = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
 #pragma unroll
     for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Vs[(16 * kb + lq + 4 * g) * 16 + lc] = v[g];
+    for (int g = 0; g < 4; ++g) Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
   }
   // backward substitution (in place in the strip: block kb is overwritten once all j > kb are final)
   for (int kb = NB - 1; kb >= 0; --kb) {
     d4_t acc;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = Vs[(16 * kb + lq + 4 * g) * 16 + lc];
+    for (int g = 0; g < 4; ++g) acc[g] = Vs[(16 * kb + strip_row(lq, g)) * 16 + lc];
     for (int j = kb + 1; j < NB; ++j) {
       const double* vb = Vs + (16 * j + lq) * 16 + lc;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        // A[i = lc][k = lq] = L[16 j + 4 m + lq][16 kb + lc]  (the transposed tile)
-        const int r = 16 * j + 4 * m + lq, c = 16 * kb + lc;
+        // A[i = lc][k] = L[16 j + k][16 kb + lc] (the transposed tile), k = 4 lq + m as in the strip's row order
+        const int r = 16 * j + 4 * lq + m, c = 16 * kb + lc;
         const double a = (r < n && c < n) ? Lg[(size_t)r * N + c] : 0.0;
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
       }
@@ -132,7 +124,7 @@ __global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = 16 * kb + lq + 4 * g;
-      Vs[row * 16 + lc] = v[g];
+      Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
       if (row < N && qc < R) Og[(size_t)row * R + qc] = row < n ? v[g] : 0.0;
     }
   }
@@ -181,7 +173,24 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   // K^-1 tile: sum_r Linv[r][a] Linv[r][c], r >= 16 ta (Linv is lower triangular, a >= c)
   const int pa = 16 * ta + lc, pc = 16 * tc + lc;
   d4_t kin = {0.0, 0.0, 0.0, 0.0};
-  for (int r0 = 16 * ta; r0 < N; r0 += 4) {
+  // (16 rows per trip: the eight loads of a trip are issued together, then four MFMAs -- one exposed
+  //  memory latency per 16 rows instead of per 4)
+  const bool cols_in = 16 * ta + 16 <= N;   // then pc < pa < N for every lane
+  int r0 = 16 * ta;
+  if (cols_in) {
+    for (; r0 + 16 <= N; r0 += 16) {
+      const double* row = Li + (size_t)(r0 + lq) * N;
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = row[(size_t)4 * u * N + pa];
+        bv[u] = row[(size_t)4 * u * N + pc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kin = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], kin, 0, 0, 0);
+    }
+  }
+  for (; r0 < N; r0 += 4) {
     const int r = r0 + lq;
     const double a = (r < N && pa < N) ? Li[(size_t)r * N + pa] : 0.0;
     const double b = (r < N && pc < N) ? Li[(size_t)r * N + pc] : 0.0;

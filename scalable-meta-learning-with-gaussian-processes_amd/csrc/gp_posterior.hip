@@ -101,15 +101,7 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
     const int arow = 16 * kb + lc;
     const bool arow_ok = arow < n;
     const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    for (int j = 0; j < kb; ++j) {
-      const double* vb = Vs + (16 * j + lq) * 16 + lc;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int col = 16 * j + 4 * m + lq;
-        const double a = (arow_ok && col < n) ? Lrow[col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);  // blgp = 1: -A
-      }
-    }
+    acc = subst_accumulate(acc, Lrow, arow_ok, 16 * kb + 16 <= n, n, (N & 1) == 0, Vs, 0, kb, lc, lq);
     // V_kb = W_kb acc: register m of acc is row 4m + lq of the tile = the B operand of k-step m
     d4_t v = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
@@ -118,7 +110,7 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       var_part = __builtin_fma(v[g], v[g], var_part);
-      Vs[(16 * kb + lq + 4 * g) * 16 + lc] = v[g];
+      Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
       const int row = 16 * kb + lq + 4 * g;
       if (p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = v[g];
     }

@@ -89,4 +89,46 @@ __device__ __forceinline__ double kernel_from_sqdist(double d2, const double* ex
   }
 }
 
+// ---- blocked forward substitution on the matrix cores (posterior, L^-1, Cholesky solve) ----------
+// One rank-16 step: acc -= L[16 kb + lc][16 j .. 16 j + 15] * V_j with V_j (16 rows x 16 right-hand sides)
+// in the wave's LDS strip.  The contraction index is taken in the order k = 4 lq + m (lane group lq, MFMA
+// k-step m) instead of 4 m + lq: a lane then needs FOUR CONTIGUOUS doubles of its row of L -- 128-byte
+// row segments across the wave, two 16-byte loads per lane instead of four scattered 8-byte ones.  The
+// strip is stored with the matching row permutation inside each 16-row block (row 4a + b at position
+// 4b + a, see strip_row), which keeps the B-operand reads at the conflict-free stride.
+struct LRowSeg {
+  double a[4];
+};
+__device__ __forceinline__ int strip_row(int lq, int g) { return 4 * lq + g; }  // storage row of tile row lq + 4g
+
+// vec: wave-uniform "whole tile in range and 16-byte aligned" (16 kb + 16 <= n, 16 j + 16 <= n, N even)
+__device__ __forceinline__ LRowSeg load_lrow_seg(const double* Lrow, int col0, bool vec, bool row_ok, int n) {
+  LRowSeg t;
+  if (vec) {
+    const double2 x = *reinterpret_cast<const double2*>(Lrow + col0);
+    const double2 y = *reinterpret_cast<const double2*>(Lrow + col0 + 2);
+    t.a[0] = x.x; t.a[1] = x.y; t.a[2] = y.x; t.a[3] = y.y;
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) t.a[m] = (row_ok && col0 + m < n) ? Lrow[col0 + m] : 0.0;
+  }
+  return t;
+}
+
+// acc -= sum_{j = j0}^{kb-1} L[kb, j] V_j, the L row segments double-buffered one block ahead
+__device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
+                                                 const double* Vs, int j0, int kb, int lc, int lq) {
+  if (j0 >= kb) return acc;
+  LRowSeg cur = load_lrow_seg(Lrow, 16 * j0 + 4 * lq, rows_in && n_even && 16 * j0 + 16 <= n, row_ok, n);
+  for (int j = j0; j < kb; ++j) {
+    LRowSeg nxt = cur;
+    if (j + 1 < kb) nxt = load_lrow_seg(Lrow, 16 * (j + 1) + 4 * lq, rows_in && n_even && 16 * (j + 1) + 16 <= n, row_ok, n);
+    const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[m], vb[4 * m * 16], acc, 0, 0, 1);  // blgp = 1: -A
+    cur = nxt;
+  }
+  return acc;
+}
+
 }  // namespace scaml

@@ -311,7 +311,11 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N};
     size_t psize = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-    e = hipModuleLaunchKernel(m.linv, (unsigned)((nb + waves - 1) / waves), (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
+    // one workgroup per task takes all strips (balanced over its waves); small stacks are split over more
+    // workgroups so that the 256 CUs stay busy
+    int groups = 1;
+    while (groups * 2 * waves <= nb && (long long)T * groups * 2 <= 256) groups *= 2;
+    e = hipModuleLaunchKernel(m.linv, (unsigned)groups, (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
                               (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_linv)", e); return SCAML_E_LAUNCH; }
   }
