@@ -559,6 +559,38 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     __syncthreads();
     STAMP(2);
 
+    // One finished sub-diagonal tile (ti, c): read back from the LDS column buffer in row segments -> HBM as
+    // 128-byte stores; the mirrored upper tile is written as zeros by the same lanes on request (no
+    // separate zero-fill pass over L).
+    auto store_tile = [&](int c, int ti) {
+      const double* prow = PT + (c & 1) * PANEL + (16 * ti + lq) * PP + lc;
+      const double e[4] = {prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]};
+      double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c);   // tile (ti, c), wave-uniform
+      double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti);   // mirrored tile (c, ti)
+      if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          tb[(size_t)g * 4 * N + lane_idx] = e[g];
+          if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+        }
+      } else {
+        const int col = 16 * c + lc, mc = 16 * ti + lc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * ti + lq + 4 * g, mr = 16 * c + lq + 4 * g;
+          if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
+          if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+        }
+      }
+    };
+    // The first PSTORE columns go to HBM from the panel wave: in the early panels it runs a whole step ahead
+    // of the update waves (which are the bottleneck there) and has the time; later it is the bottleneck
+    // itself and the update waves store their own tiles.
+#ifndef SCAML_PSTORE
+#define SCAML_PSTORE 12
+#endif
+    constexpr int PSTORE = (WU == 7 && NB == 16) ? SCAML_PSTORE : 0;
+
     if (is_panel) {
       // ================= panel wave: the chain of diagonal blocks, running ahead of the update =========
       // (it is the youngest wave on its SIMD and would lose every issue slot to the update wave
@@ -570,6 +602,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         // owners during U1(j-2): one whole step of slack, the chain does not wait in steady state
         if (j >= 2) sync_wait_ge(cntS + j - 2, WU);
         STAMP(3);
+        // (cntS[j-2] complete: column j-2 is final in its LDS buffer, which F(j) reuses after flagW[j])
+        if (Lg && j >= 2 && j - 2 < PSTORE)
+          for (int ti = j - 1; ti < NB; ++ti) store_tile(j - 2, ti);
         d4_t a;
         {
           const double* dg = DG + (j & 1) * 256 + lane;   // symmetric: the transposed image is the block
@@ -604,35 +639,12 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       __builtin_amdgcn_s_setprio(0);
     } else {
       // ================= update waves ================================================================
-      // Finished sub-diagonal tiles of column c: read back from the LDS panel in row segments -> HBM as
-      // 128-byte stores; the mirrored upper tile is written as zeros by the same lanes (no separate
-      // zero-fill pass over L).
       auto store_column = [&](int c) {
-        if (Lg) {
-          const double* buf = PT + (c & 1) * PANEL;
+        if (Lg && c >= PSTORE) {
           const int sa = slo(c), sb = slo(c + 1), offc = off(c);
           for (int s = sa; s < sb; ++s) {
             const int ti = c + (s * WU + wave - offc);
-            if (ti == c) continue;   // the diagonal tile: store_diag
-            const double* prow = buf + (16 * ti + lq) * PP + lc;
-            const double e[4] = {prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]};
-            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c);   // tile (ti, c), wave-uniform
-            double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti);   // mirrored tile (c, ti)
-            if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-              }
-            } else {
-              const int col = 16 * c + lc, mc = 16 * ti + lc;
-#pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int row = 16 * ti + lq + 4 * g, mr = 16 * c + lq + 4 * g;
-                if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
-                if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
-              }
-            }
+            if (ti != c) store_tile(c, ti);   // (the diagonal tile: store_diag)
           }
         }
       };

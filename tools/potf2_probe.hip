@@ -6,11 +6,10 @@
 #include <vector>
 using namespace scaml;
 __global__ void probe(double* out, long long* cyc, int reps, int noisy) {
-  __shared__ double panel[64 * PP + 16 * PP + 256];
-  double* Wk = panel + 64 * PP; double* vv = Wk + 16 * PP; double* trash = vv + 64; double* ytil = trash + 64;
+  __shared__ double panel[64 * PP + 2 * 16 * PP + 256];
+  double* Wk = panel + 64 * PP; double* LT = Wk + 16 * PP; double* trash = LT + 16 * PP;   // trash: [80] dump slots + [16] pivot log
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 64 * PP; i += blockDim.x) { int r = i / PP, c = i % PP; panel[i] = (r == c ? 20.0 : 0.0) + 1.0 / (1 + r + c); }
-  if (tid < 64) ytil[tid] = 0.1 * tid;
   __syncthreads();
   if (wave == 0) {
     __builtin_amdgcn_s_setprio(3);
@@ -19,10 +18,12 @@ __global__ void probe(double* out, long long* cyc, int reps, int noisy) {
     for (int r = 0; r < reps; ++r) {
       // refill the block so every repetition factors the same SPD matrix
       for (int i = lane; i < 16 * PP; i += 64) { int rr = i / PP, c = i % PP; panel[i] = (rr == c ? 20.0 : 0.0) + 1.0 / (1 + rr + c); }
-      bad |= potf2_inv_block(panel, Wk, vv, trash, ytil, 0, lane);
+      d4_t a;
+      for (int g = 0; g < 4; ++g) a[g] = panel[((lane >> 4) + 4 * g) * PP + (lane & 15)];
+      bad |= potf2_inv_block(a, LT, Wk, trash, 0, lane);
     }
     long long t1 = __builtin_amdgcn_s_memtime();
-    if (lane == 0) { cyc[0] = (t1 - t0) / reps; out[0] = vv[3] + bad; }
+    if (lane == 0) { cyc[0] = (t1 - t0) / reps; out[0] = LT[3 * PP + 1] + Wk[2] + bad; }
   } else if (noisy) {
     // a co-resident wave streaming dependent MFMAs (like an update wave in U2)
     d4_t acc = {0, 0, 0, 0}; double a = 1.0 + lane * 1e-3, b = 0.5;
