@@ -356,8 +356,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* CR = DG + 2 * 256;
   double* LT = CR + 2 * 256;
   constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
-  // (during the build: xsT, then up to 15 tile images written by the panel wave, see PANEL_BUILDS)
-  const int buildA = p.D * NP + 2 + 15 * 256;
+  // (during the build: xsT, then up to 24 tile images written by the panel wave, see PANEL_BUILDS)
+  const int buildA = p.D * NP + 2 + 24 * 256;
   const int regionA = (buildA > REGION_A) ? buildA : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
@@ -485,16 +485,23 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       }
     };
     // The build is VALU work, two waves per SIMD -- except on the SIMD of the (otherwise idle) panel
-    // wave.  With 7 update waves the panel wave therefore builds the tiles of slots >= KSLOT of the six
-    // update waves that do not share its SIMD (15 of the 136 tiles) into LDS images, which their owners
-    // pick up after the barrier: every SIMD then evaluates 34 tiles.
+    // wave.  With 7 update waves the panel wave therefore builds the last slots of the six update waves that
+    // do not share its SIMD into LDS images, which their owners pick up after the barrier.  The second wave
+    // of a SIMD (4, 5, 6) only gets the issue slots its older mate leaves (measured 3.0 k cycles per tile
+    // against 2.6 k; the panel wave 3.8 k), so it hands over three tiles (slots 16..18) and the first waves
+    // one (slot 19): 12 of the 136 tiles, and all waves finish within a few per cent of each other.
     constexpr bool PANEL_BUILDS = (WU == 7 && NB == 16);
-    constexpr int KSLOT = 17, KMATE = 3;   // wave KMATE shares the panel wave's SIMD (waves go round-robin)
-    double* KT = lds + ((D * NP + 1) & ~1);   // [15][256] register images, behind xsT
+    constexpr int KMATE = 3;   // wave KMATE shares the panel wave's SIMD (waves go round-robin)
+#ifndef SCAML_KOLD
+#define SCAML_KOLD 19
+#define SCAML_KYOUNG 16
+#endif
+    auto kslot_of = [](int w) { return w < KMATE ? SCAML_KOLD : SCAML_KYOUNG; };
+    double* KT = lds + ((D * NP + 1) & ~1);   // [6][4][256] register images, behind xsT
     if (!is_panel) {
       int kj = 0, kr = wave;  // column / row-in-column of the current slot's tile
 #define SCAML_KBUILD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
-      if (S < SLOTS && !(PANEL_BUILDS && S >= KSLOT && wave != KMATE)) {                           \
+      if (S < SLOTS && !(PANEL_BUILDS && wave != KMATE && S >= kslot_of(wave))) {                  \
         while (kj < NB && kr >= NB - kj) { kr -= NB - kj; ++kj; }                                  \
         if (kj < NB) {                                                                             \
           double kt[4];                                                                            \
@@ -506,10 +513,10 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       SCAML_TILE_LIST(SCAML_KBUILD_)
 #undef SCAML_KBUILD_
     } else if (PANEL_BUILDS) {
-      for (int idx = 0; idx < 6 * (SLOTS - KSLOT); ++idx) {
-        const int s = KSLOT + idx / 6, w6 = idx % 6, w = w6 + (w6 >= KMATE);
+      for (int idx = 0; idx < 6 * 4; ++idx) {
+        const int w6 = idx >> 2, w = w6 + (w6 >= KMATE), s = kslot_of(w) + (idx & 3);
         const int t = s * WU + w;
-        if (t >= NT) continue;
+        if (s >= SLOTS || t >= NT) continue;
         int kj = 0, kr = t;
         while (kr >= NB - kj) { kr -= NB - kj; ++kj; }
         double kt[4];
@@ -525,8 +532,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     if (PANEL_BUILDS && !is_panel && wave != KMATE) {
       const int w6 = wave - (wave > KMATE);
 #define SCAML_KLOAD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                            \
-      if (S >= KSLOT && S < SLOTS && S * WU + wave < NT) {                                         \
-        const double* img = KT + ((S - KSLOT) * 6 + w6) * 256 + lane;                              \
+      if (S >= kslot_of(wave) && S < SLOTS && S * WU + wave < NT) {                                \
+        const double* img = KT + (w6 * 4 + (S - kslot_of(wave))) * 256 + lane;                     \
         TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, img[0], img[64], img[128], img[192]);             \
       }
       SCAML_TILE_LIST(SCAML_KLOAD_)

@@ -95,7 +95,7 @@ Module& module() {
 size_t fit_lds_bytes(int nb, int wu, int D) {
   const int np = nb * 16;
   size_t regionA = (size_t)2 * np * PP + (size_t)(nb + 2) * 16 * PP + 4 * 256;   // PT[2], WAll[nb], LT[2], DG[2], CR[2]
-  const size_t buildA = (size_t)D * np + 2 + 15 * 256;   // X/l transposed + the panel wave's tile images
+  const size_t buildA = (size_t)D * np + 2 + 24 * 256;   // X/l transposed + the panel wave's tile images
   if (buildA > regionA) regionA = buildA;
   // + vectors, trash/exp table, row lists, 1/l, fail flag + 6 nb hand-off counters (ints)
   return (regionA + 4 * np + 160 + (size_t)wu * nb * 4 + (size_t)wu * 16 + D + (D & 1) + 2 + 3 * (size_t)nb) * sizeof(double);
