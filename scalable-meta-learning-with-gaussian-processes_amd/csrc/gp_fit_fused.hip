@@ -290,39 +290,6 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, d
 
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
 
-// x summed over the four lane groups lq (lanes l, l^16, l^32, l^48), result in every lane: gfx950's
-// v_permlane{32,16}_swap exchange half-waves / odd-even rows in one VALU op per dword (no LDS crossbar)
-__device__ __forceinline__ double sum_lane_groups(double x) {
-  {
-    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  }
-  {
-    const unsigned lo = __double2loint(x), hi = __double2hiint(x);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-  }
-  return x;
-}
-
-// sum over the 16 lanes of a DPP row (same lq): the total lands in lane lc == 15
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double row_sum_to_lane15(double x) {
-  x += dpp_mov_f64<0x118>(x);   // row_shr:8
-  x += dpp_mov_f64<0x114>(x);   // row_shr:4
-  x += dpp_mov_f64<0x112>(x);   // row_shr:2
-  x += dpp_mov_f64<0x111>(x);   // row_shr:1
-  return x;
-}
-
 // switch-dispatch of one runtime slot index onto the code for the matching physical tile
 #define SCAML_CASE_(S, r0, r1, r2, r3, r4, r5, r6, r7) \
   case S:                                              \

@@ -150,14 +150,25 @@ __device__ __forceinline__ void kernel_and_dfactor(double d2, const double* expt
 template <int KIND>
 __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   __shared__ double exptab[64];
+  __shared__ double invl_s[64];   // 1 / lengthscale (D <= 64: larger D take the division)
+  extern __shared__ double xstage[];   // [waves][32][D] scaled points of the two blocks of a tile
   const int N = p.N, D = p.D, NB = (N + 15) / 16;
-  const int task = blockIdx.y;
+  const int NT = NB * (NB + 1) / 2;
+  // XCD-aware block -> (task, tile group) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
+  // each XCD has its own 4 MB L2: all tile groups of one task are therefore given ids that are congruent
+  // mod 8, so that the task's L^-1 (re-read by every tile of its column / row) stays in ONE L2 instead of
+  // being fetched from HBM by all eight.  1-D grid of ceil(T / 8) * 8 * groups blocks.
+  const int groups = (NT + 3) / 4;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int task = (slot / groups) * 8 + xcd;
+  const int group = slot % groups;
+  if (task >= p.T) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   exp2_table_init(exptab, tid);
+  if (tid < D && tid < 64) invl_s[tid] = 1.0 / p.theta[(size_t)task * (D + 2) + tid];
   __syncthreads();
-  const int NT = NB * (NB + 1) / 2;
-  const int tile = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int tile = group * (blockDim.x >> 6) + wave;
   if (tile >= NT) return;
   // tile -> (ta >= tc), column-major over the lower triangle
   int tc = 0, off = 0;
@@ -196,55 +207,54 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
     const double b = (r < N && pc < N) ? Li[(size_t)r * N + pc] : 0.0;
     kin = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, kin, 0, 0, 0);
   }
-  // epilogue: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc
+  // epilogue: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc.  The 32 points of the two
+  // blocks are staged (scaled by 1 / l) in the wave's LDS slab, so that both passes over the dimensions are
+  // LDS reads, and the D + 2 sums are reduced over the wave at the very end, back to back.
   const double wgt = ta == tc ? 1.0 : 2.0;
-  double g_os = 0.0, g_noise = 0.0;
   double* outp = p.partials + ((size_t)task * NT + tile) * (D + 2);
+  double* xs = xstage + (size_t)wave * 32 * D;   // [32][D]: rows 0..15 block ta, 16..31 block tc
+  for (int e = lane; e < 32 * D; e += 64) {
+    const int r = e / D, d = e - r * D;
+    const int row = (r < 16 ? 16 * ta : 16 * tc - 16) + r;
+    const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
+    xs[e] = row < n ? Xg[(size_t)row * D + d] * il : 0.0;
+  }
+  // (same wave writes and reads: LDS is in order, no barrier needed)
   const double ac = pc < n ? al[pc] : 0.0;
   double G[4], hk[4];
+  double g_os = 0.0, g_noise = 0.0;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int a = 16 * ta + lq + 4 * g;
     const bool ok = a < n && pc < n;
     double d2 = 0.0;
-    if (ok) {
-      for (int d = 0; d < D; ++d) {
-        const double df = (Xg[(size_t)a * D + d] - Xg[(size_t)pc * D + d]) / th[d];
-        d2 = __builtin_fma(df, df, d2);
-      }
+    for (int d = 0; d < D; ++d) {
+      const double df = xs[(lq + 4 * g) * D + d] - xs[(16 + lc) * D + d];
+      d2 = __builtin_fma(df, df, d2);
     }
     double k, h;
     kernel_and_dfactor<KIND>(d2, exptab, k, h);
-    const double Gv = ok ? wgt * (al[a] * ac - kin[g]) : 0.0;
-    G[g] = Gv;
+    const double Gv = ok ? wgt * (al[a < N ? a : 0] * ac - kin[g]) : 0.0;
+    G[g] = Gv * os;   // (os folded in: every lengthscale term carries it)
     hk[g] = h;
     g_os = __builtin_fma(Gv, k, g_os);
     if (a == pc) g_noise += Gv;
   }
-  // lengthscales: sum G os h delta_d^2 / l_d^3
+  // lengthscales: d mll / d l_d ~ sum G os h delta_d^2 / l_d^3 with delta / l already in LDS: sum G os h (delta/l)^2 / l
   for (int d = 0; d < D; ++d) {
-    const double l = th[d];
-    const double il3 = 1.0 / (l * l * l);
     double s = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int a = 16 * ta + lq + 4 * g;
-      if (a < n && pc < n) {
-        const double df = Xg[(size_t)a * D + d] - Xg[(size_t)pc * D + d];
-        s = __builtin_fma(G[g] * hk[g], df * df, s);
-      }
+      const double df = xs[(lq + 4 * g) * D + d] - xs[(16 + lc) * D + d];
+      s = __builtin_fma(G[g] * hk[g], df * df, s);
     }
-    s *= os * il3;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) outp[d] = s;
+    const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
+    s = wave_sum_to_lane15(s * il);
+    if (lane == 63) outp[d] = s;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    g_os += __shfl_xor(g_os, o);
-    g_noise += __shfl_xor(g_noise, o);
-  }
-  if (lane == 0) {
+  g_os = wave_sum_to_lane15(g_os);
+  g_noise = wave_sum_to_lane15(g_noise);
+  if (lane == 63) {
     outp[D] = g_os;        // = sum G k  (d K / d os = k)
     outp[D + 1] = g_noise; // = tr G
   }

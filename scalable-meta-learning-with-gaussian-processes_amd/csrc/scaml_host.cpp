@@ -323,7 +323,10 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     scaml::MllGradParams p{X, theta, alpha, Linv, n_points, partials, T, N, D};
     size_t psize = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-    e = hipModuleLaunchKernel(m.mllgrad[kind], (unsigned)((nt + 3) / 4), (unsigned)T, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+    // 1-D grid, XCD-aware (task, tile group) map inside the kernel
+    const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * (unsigned)((nt + 3) / 4);
+    e = hipModuleLaunchKernel(m.mllgrad[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(4 * 32 * D * sizeof(double)), (hipStream_t)stream,
+                              nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad)", e); return SCAML_E_LAUNCH; }
   }
   return SCAML_OK;
