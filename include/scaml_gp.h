@@ -129,6 +129,21 @@ int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double*
                             int T, int N, int M, int Ma, int D, int kind, double* cov, unsigned flags, void* stream);
 
 /*
+ * (5c) The explicit inverse factor Linv = L^-1 (T, N, N; zero above the diagonal; identity rows past n_t) of a
+ * fused fit / POTRF, and the source posteriors computed from it.  gpytorch keeps such a cache
+ * (DefaultPredictionStrategy.covar_cache, the root of K^-1) for fast predictive variances; here it turns
+ * V = L^-1 K_*^T from a substitution with a serial dependency into a triangular matrix product, which is what
+ * the BO loop wants: the source GPs of scamlgp/model.py:128, :281 are fixed while every acquisition step
+ * scores thousands of candidates.  scaml_posterior_linv_f64 has the semantics of
+ * scaml_posterior_batched_f64 (same mu, var, V; SCAML_POST_XQ_PER_TASK allowed, SCAML_POST_MEAN_ONLY not).
+ */
+int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N, double* Linv,
+                           void* stream);
+int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                             const double* y_mean, const double* y_std, const int32_t* n_points, int T, int N, int M, int D,
+                             int kind, double* mu, double* var, double* V, unsigned flags, void* stream);
+
+/*
  * Batched Cholesky solve Xout = (L L^T)^-1 B for R right-hand sides per task, B and Xout (T, N, R), with
  * the L and Linv_diag of a fused fit / POTRF (gpytorch's cholesky_solve behind prediction caches and
  * inv_quad for new right-hand sides).  Forward and backward substitution as blocked MFMA products.

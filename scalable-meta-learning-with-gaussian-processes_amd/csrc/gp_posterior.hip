@@ -125,6 +125,124 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
   }
 }
 
+// gp_posterior_linv_kernel: the same posteriors from the EXPLICIT inverse factor L^-1 (scaml_linv_batched_f64,
+// computed once per fit -- the source GPs of a BO run are fixed while thousands of candidates are scored):
+// V = L^-1 K_*^T is then a triangular matrix product with no dependency between its row blocks instead of a
+// substitution.  One workgroup (4 waves) per (task, strip of 16 query points): the waves first evaluate the
+// cross-kernel strip K_*^T (N x 16) into LDS side by side (VALU work, four row blocks each), then take the
+// output row blocks in boustrophedon order (block kb costs kb + 1 products: 0,7,8,15 | 1,6,9,14 | ... is
+// perfectly balanced) and stream the rows of L^-1 through the matrix cores (128-byte row segments, one block
+// ahead).  LDS is 37-53 KB per workgroup, so three to four of them share a CU and hide each other's
+// latencies -- the substitution kernel above holds a 32 KB strip per WAVE and runs one wave per SIMD.
+// XCD-aware block map (see gp_mll_grad_kernel): the strips of one task share an L2.
+template <int KIND>
+__global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams p) {
+  extern __shared__ double lds[];
+  const int N = p.N, D = p.D, M = p.M;
+  const int NB = (N + 15) / 16, NP = NB * 16;
+  const int strips = (M + 15) / 16;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int task = (slot / strips) * 8 + xcd;
+  const int strip = slot % strips;
+  if (task >= p.T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, lq = lane >> 4;
+  int n = p.n_points ? p.n_points[task] : N;
+  n = n < 0 ? 0 : (n > N ? N : n);
+  // LDS: exp table [64] | alpha [NP] | invl [D] (+pad) | xq [D][16] | red [32] | K_*^T strip [NP][16] | xsT [D][NP] (optional)
+  double* exptab = lds;
+  double* alpha_s = exptab + 64;
+  double* invl = alpha_s + NP;
+  double* xqs = invl + D + (D & 1);
+  double* red = xqs + 16 * D;
+  double* Ks = red + 32;
+  double* xsT = Ks + NP * 16;
+
+  const double* Xg = p.X + (size_t)task * N * D;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double* Li = p.L + (size_t)task * N * N;   // L^-1 here
+  const double os = th[D];
+  const double ym = p.y_mean ? p.y_mean[task] : 0.0;
+  const double ys = p.y_std ? p.y_std[task] : 1.0;
+  const int qc = 16 * strip + lc;   // this lane's query point
+
+  exp2_table_init(exptab, tid);
+  if (tid < D) invl[tid] = 1.0 / th[tid];
+  if (tid < 32) red[tid] = 0.0;
+  for (int r = tid; r < NP; r += blockDim.x) alpha_s[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
+  __syncthreads();
+  if (p.x_in_lds) {
+    for (int r = tid; r < NP; r += blockDim.x) {
+      const bool in = r < n;
+      for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+    }
+  }
+  if (tid < 16) {
+    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
+    for (int d = 0; d < D; ++d) xqs[d * 16 + lc] = qc < M ? Xqg[(size_t)qc * D + d] * invl[d] : 0.0;
+  }
+  __syncthreads();
+
+  // ---- phase 1: cross-kernel strip into LDS (rows permuted inside each 16-block, see strip_row) + the mean
+  double mean_part = 0.0;
+  for (int kb = wave; kb < NB; kb += 4) {
+    double d2[4] = {0.0, 0.0, 0.0, 0.0};
+    const int row0 = 16 * kb + lq;
+#pragma unroll 2
+    for (int d = 0; d < D; ++d) {
+      const double xc = xqs[d * 16 + lc];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = row0 + 4 * g;
+        const double xr = p.x_in_lds ? xsT[d * NP + row] : (row < n ? Xg[(size_t)row * D + d] * invl[d] : 0.0);
+        const double df = xr - xc;
+        d2[g] = __builtin_fma(df, df, d2[g]);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = row0 + 4 * g;
+      double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+      kv = row < n ? kv : 0.0;
+      Ks[(16 * kb + strip_row(lq, g)) * 16 + lc] = kv;
+      mean_part = __builtin_fma(kv, alpha_s[row], mean_part);
+    }
+  }
+  mean_part = sum_lane_groups(mean_part);
+  if (lq == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(red + lc), mean_part);
+  __syncthreads();
+
+  // ---- phase 2: V = L^-1 K_*^T by row blocks, the variance on the fly
+  if (!p.mean_only) {
+    double var_part = 0.0;
+    const bool n_even = (N & 1) == 0;
+    for (int it = 0;; ++it) {
+      const int kb = (it & 1) ? (it + 1) * 4 - 1 - wave : it * 4 + wave;
+      if (kb >= NB) {
+        if (it * 4 >= NB) break;
+        continue;
+      }
+      const int arow = 16 * kb + lc;
+      const double* Lrow = Li + (size_t)(arow < N ? arow : 0) * N;
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      acc = block_row_accumulate<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        var_part = __builtin_fma(acc[g], acc[g], var_part);
+        const int row = 16 * kb + lq + 4 * g;
+        if (p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = row < n ? acc[g] : 0.0;
+      }
+    }
+    var_part = sum_lane_groups(var_part);
+    if (lq == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(red + 16 + lc), var_part);
+    __syncthreads();
+  }
+  if (tid < 16 && qc < M) {
+    if (p.mu) p.mu[(size_t)task * M + qc] = __builtin_fma(ys, red[tid], ym);
+    if (p.var) p.var[(size_t)task * M + qc] = ys * ys * (os - red[16 + tid]);
+  }
+}
+
 // cov[t][a][c] = s_t^2 (os k(xq_a, xq_c) - sum_i V[t][i][a] V[t][i][c]) for a < Ma, c < M:
 // one wave per 16x16 output tile, contraction over the N training points on the matrix cores.
 template <int KIND>
@@ -216,3 +334,5 @@ __global__ void gp_kernel_matrix_kernel(scaml::KernelMatrixParams p) {
 }
 template __global__ void gp_kernel_matrix_kernel<0>(scaml::KernelMatrixParams);
 template __global__ void gp_kernel_matrix_kernel<1>(scaml::KernelMatrixParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1>(scaml::PosteriorParams);

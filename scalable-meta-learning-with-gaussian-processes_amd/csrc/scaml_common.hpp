@@ -151,9 +151,10 @@ __device__ __forceinline__ LRowSeg load_lrow_seg(const double* Lrow, int col0, b
   return t;
 }
 
-// acc -= sum_{j = j0}^{kb-1} L[kb, j] V_j, the L row segments double-buffered one block ahead
-__device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
-                                                 const double* Vs, int j0, int kb, int lc, int lq) {
+// acc -/+= sum_{j = j0}^{kb-1} L[kb, j] V_j, the L row segments double-buffered one block ahead
+template <bool NEG>
+__device__ __forceinline__ d4_t block_row_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
+                                                     const double* Vs, int j0, int kb, int lc, int lq) {
   if (j0 >= kb) return acc;
   LRowSeg cur = load_lrow_seg(Lrow, 16 * j0 + 4 * lq, rows_in && n_even && 16 * j0 + 16 <= n, row_ok, n);
   for (int j = j0; j < kb; ++j) {
@@ -161,10 +162,15 @@ __device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, b
     if (j + 1 < kb) nxt = load_lrow_seg(Lrow, 16 * (j + 1) + 4 * lq, rows_in && n_even && 16 * (j + 1) + 16 <= n, row_ok, n);
     const double* vb = Vs + (16 * j + lq) * 16 + lc;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[m], vb[4 * m * 16], acc, 0, 0, 1);  // blgp = 1: -A
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[m], vb[4 * m * 16], acc, 0, 0, NEG ? 1 : 0);  // blgp = 1: -A
     cur = nxt;
   }
   return acc;
+}
+
+__device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
+                                                 const double* Vs, int j0, int kb, int lc, int lq) {
+  return block_row_accumulate<true>(acc, Lrow, row_ok, rows_in, n, n_even, Vs, j0, kb, lc, lq);
 }
 
 }  // namespace scaml

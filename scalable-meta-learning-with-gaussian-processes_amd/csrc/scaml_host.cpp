@@ -41,6 +41,7 @@ struct Module {
   FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 1, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
+  hipFunction_t post_linv[2] = {nullptr, nullptr};
   hipFunction_t wsum = nullptr;
   hipFunction_t linv = nullptr;
   hipFunction_t kmat[2] = {nullptr, nullptr};
@@ -69,6 +70,9 @@ struct Module {
       if ((e = hipFuncSetAttribute((const void*)post[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
       snprintf(name, sizeof(name), "_ZN5scaml23gp_posterior_cov_kernelILi%dEEEvNS_18PosteriorCovParamsE", kind);
       if ((e = hipModuleGetFunction(&post_cov[kind], mod, name)) != hipSuccess) return e;
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dEEEvNS_15PosteriorParamsE", kind);
+      if ((e = hipModuleGetFunction(&post_linv[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)post_linv[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&linv, mod, "_ZN5scaml14gp_linv_kernelENS_10LinvParamsE")) != hipSuccess) return e;
@@ -286,6 +290,65 @@ int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const 
   return SCAML_OK;
 }
 
+// ---- explicit inverse factor + posteriors from it -------------------------------------------------
+static int launch_linv(Module& m, const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N,
+                       double* Linv, void* stream) {
+  const int nb = (N + 15) / 16, np = nb * 16;
+  const int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
+  scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  // one workgroup per task takes all strips (balanced over its waves); small stacks are split over more
+  // workgroups so that the 256 CUs stay busy
+  int groups = 1;
+  while (groups * 2 * waves <= nb && (long long)T * groups * 2 <= 256) groups *= 2;
+  hipError_t e = hipModuleLaunchKernel(m.linv, (unsigned)groups, (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
+                                       (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_linv)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N, double* Linv,
+                           void* stream) {
+  if (T < 0 || N < 1) return SCAML_E_BADARG;
+  if (!L || !Linv_diag || !Linv) return SCAML_E_BADARG;
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  return launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
+}
+
+int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                             const double* y_mean, const double* y_std, const int32_t* n_points, int T, int N, int M, int D,
+                             int kind, double* mu, double* var, double* V, unsigned flags, void* stream) {
+  if (T < 0 || N < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
+  if (!Xq || !X || !theta || !Linv || !alpha) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (flags & SCAML_POST_MEAN_ONLY) return SCAML_E_BADARG;   // (use scaml_posterior_batched_f64 for that)
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0 || M == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  const int np = ((N + 15) / 16) * 16;
+  const size_t base = (size_t)(64 + np + D + (D & 1) + 16 * D + 32 + (size_t)np * 16) * sizeof(double);
+  const size_t with_x = base + (size_t)D * np * sizeof(double);
+  const bool xl = with_x <= 80 * 1024;   // keep at least two workgroups per CU
+  if (base > 160 * 1024) return SCAML_E_TOOLARGE;
+  scaml::PosteriorParams p{Xq, X, theta, Linv, nullptr, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0,
+                           (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  const unsigned strips = (unsigned)((M + 15) / 16);
+  const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * strips;   // XCD-aware (task, strip) map inside the kernel
+  e = hipModuleLaunchKernel(m.post_linv[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
+                            nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
 // ---- (4) gradient of the marginal log-likelihood ------------------------------------------------
 long long scaml_mll_backward_workspace_doubles(int T, int N, int D) {
   const long long nb = (N + 15) / 16;
@@ -303,21 +366,12 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
   Module& m = module();
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
-  const int nb = (N + 15) / 16, np = nb * 16, nt = nb * (nb + 1) / 2;
+  const int nb = (N + 15) / 16, nt = nb * (nb + 1) / 2;
   double* Linv = workspace;
   double* partials = partials_out ? partials_out : workspace + (size_t)T * N * N;
-  int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
   {
-    scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N};
-    size_t psize = sizeof(p);
-    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-    // one workgroup per task takes all strips (balanced over its waves); small stacks are split over more
-    // workgroups so that the 256 CUs stay busy
-    int groups = 1;
-    while (groups * 2 * waves <= nb && (long long)T * groups * 2 <= 256) groups *= 2;
-    e = hipModuleLaunchKernel(m.linv, (unsigned)groups, (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
-                              (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
-    if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_linv)", e); return SCAML_E_LAUNCH; }
+    const int rc = launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
+    if (rc != SCAML_OK) return rc;
   }
   {
     scaml::MllGradParams p{X, theta, alpha, Linv, n_points, partials, T, N, D};

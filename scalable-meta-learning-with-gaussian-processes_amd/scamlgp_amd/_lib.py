@@ -76,6 +76,14 @@ def _load() -> ctypes.CDLL:
     ]
     lib.scaml_posterior_cov_f64.restype = c_int
     lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.c_uint, c_void_p]
+    lib.scaml_linv_batched_f64.restype = c_int
+    lib.scaml_linv_batched_f64.argtypes = [_dp, _dp, _dp, c_int, c_int, _dp, c_void_p]
+    lib.scaml_posterior_linv_f64.restype = c_int
+    lib.scaml_posterior_linv_f64.argtypes = [
+        _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,  # Xq, X, theta, Linv, alpha, y_mean, y_std, n_points
+        c_int, c_int, c_int, c_int, c_int,  # T, N, M, D, kind
+        _dp, _dp, _dp, ctypes.c_uint, c_void_p,  # mu, var, V, flags, stream
+    ]
     lib.scaml_cho_solve_batched_f64.restype = c_int
     lib.scaml_cho_solve_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, c_void_p]
     lib.scaml_weighted_task_sum_f64.restype = c_int
@@ -101,6 +109,8 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_max_n",
     "scaml_posterior_batched_f64",
     "scaml_posterior_cov_f64",
+    "scaml_linv_batched_f64",
+    "scaml_posterior_linv_f64",
     "scaml_cho_solve_batched_f64",
     "scaml_weighted_task_sum_f64",
     "scaml_mll_backward_workspace_doubles",

@@ -161,6 +161,9 @@ class SourceGPStack:
         """Factor all tasks at the current hyper-parameters (one launch) and cache L, alpha, W."""
         fit = ops.gp_fit_fused(self.X, self.y, self.theta, self.kind, n_points=self.n_points, want_linv=True)
         ops.raise_if_not_psd(fit["info"])
+        # the explicit inverse factor: computed once per fit, it makes every later posterior a matrix product
+        # (the role of gpytorch's prediction-strategy caches; scamlgp/model.py:128, :281 query fixed source GPs)
+        fit["Linv"] = ops.linv_batched(fit["L"], fit["Linv_diag"], n_points=self.n_points)
         self._fit = fit
         return fit
 
@@ -193,7 +196,7 @@ class SourceGPStack:
         f = self.fit
         return ops.source_posteriors(xq.to(self.device, torch.float64), self.X, self.theta, self.kind, f["L"], f["Linv_diag"],
                                      f["alpha"], self.y_mean, self.y_std, n_points=self.n_points, want_var=want_var,
-                                     cov_first=cov_first)
+                                     cov_first=cov_first, Linv=f.get("Linv"))
 
     def raw_targets(self) -> torch.Tensor:
         """All source observations in original units, concatenated (scamlgp/model.py:264-270)."""

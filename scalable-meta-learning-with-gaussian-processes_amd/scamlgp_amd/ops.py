@@ -177,6 +177,20 @@ def _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry) -> Di
     return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info.to(torch.int32), jitter=jit, Linv_diag=linv)
 
 
+def linv_batched(L: torch.Tensor, Linv_diag: torch.Tensor, n_points: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """L^-1 (T, N, N) of the factors of a fused fit (zero above the diagonal).  scaml_linv_batched_f64."""
+    T, N, _ = L.shape
+    L = _check(L, "L", (T, N, N))
+    Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    out = torch.empty_like(L)
+    with torch.cuda.device(L.device):
+        rc = _lib.lib.scaml_linv_batched_f64(_ptr(L), _ptr(Linv_diag), _ptr(n_points), T, N, _ptr(out), _stream_handle())
+    _lib.check_rc(rc, "scaml_linv_batched_f64")
+    return out
+
+
 def cho_solve(L: torch.Tensor, Linv_diag: torch.Tensor, B: torch.Tensor, n_points: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(L L^T)^-1 B for B (T, N, R) with the factors of a fused fit.  scaml_cho_solve_batched_f64."""
     T, N, _ = L.shape
@@ -262,10 +276,13 @@ def source_posteriors(
     cov_first: int = 0,
     keep_V: bool = False,
     mean_only: bool = False,
+    Linv: Optional[torch.Tensor] = None,
 ) -> Dict[str, torch.Tensor]:
     """Posteriors of all source GPs at the shared query points Xq (M, D), or at per-task query sets
     Xq (T, M, D).  ``mean_only`` skips the triangular solve (mu = m + s K_* alpha only; L and
-    Linv_diag may be None); ``keep_V`` also returns V = L^-1 K_*^T (T, N, M).
+    Linv_diag may be None); ``keep_V`` also returns V = L^-1 K_*^T (T, N, M).  With ``Linv`` (T, N, N) from
+    ``linv_batched`` the posteriors come from the explicit inverse factor (scaml_posterior_linv_f64: a
+    triangular matrix product instead of a substitution -- the fast path when one fit serves many queries).
 
     Returns dict(mean (T, M), var (T, M) or None, cov (T, cov_first, M) or None): ``cov`` is the
     posterior covariance between the first ``cov_first`` query points and all of them (put the
@@ -289,7 +306,7 @@ def source_posteriors(
     if mean_only:
         flags |= _lib.POST_MEAN_ONLY
         want_var, cov_first, keep_V, L, Linv_diag = False, 0, False, None, None
-    else:
+    elif Linv is None:
         L = _check(L, "L", (T, N, N))
         Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
     alpha = _check(alpha, "alpha", (T, N))
@@ -306,10 +323,17 @@ def source_posteriors(
         mu = torch.empty((T, M), dtype=torch.float64, device=dev)
         var = torch.empty((T, M), dtype=torch.float64, device=dev) if want_var else None
         V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if (cov_first > 0 or keep_V) else None
-        rc = _lib.lib.scaml_posterior_batched_f64(
+        if Linv is not None and not mean_only:
+            Linv = _check(Linv, "Linv", (T, N, N))
+            rc = _lib.lib.scaml_posterior_linv_f64(
+                _ptr(Xq), _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean), _ptr(y_std), _ptr(n_points),
+                T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), flags, _stream_handle())
+            _lib.check_rc(rc, "scaml_posterior_linv_f64")
+        else:
+            rc = _lib.lib.scaml_posterior_batched_f64(
             _ptr(Xq), _ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(y_mean), _ptr(y_std),
-            _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), flags, _stream_handle())
-        _lib.check_rc(rc, "scaml_posterior_batched_f64")
+                _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), flags, _stream_handle())
+            _lib.check_rc(rc, "scaml_posterior_batched_f64")
         cov = None
         if cov_first > 0:
             cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)

@@ -99,3 +99,38 @@ def test_weighted_task_sum_and_pruning_mask(device):
     torch.testing.assert_close(mu.cpu(), mu_ref, rtol=1e-14, atol=1e-15)
     torch.testing.assert_close(cov.cpu().reshape(-1), cov_ref, rtol=1e-14, atol=1e-15)
     torch.testing.assert_close(ops.weighted_task_sum(mus.to(device), w.to(device)).cpu(), (w[:, None] * mus).sum(0))
+
+
+@pytest.mark.parametrize("T,N,D,M,kind", [(3, 48, 3, 21, O.KIND_RBF), (2, 100, 5, 40, O.KIND_MATERN52), (2, 256, 8, 33, O.KIND_MATERN52),
+                                           (2, 400, 6, 17, O.KIND_RBF)])
+def test_posterior_from_explicit_inverse_matches_substitution_and_oracle(T, N, D, M, kind, device):
+    """scaml_linv_batched_f64 + scaml_posterior_linv_f64 against the substitution kernel and the oracle."""
+    g = torch.Generator().manual_seed(N + M)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g)
+    y = torch.randn(T, N, dtype=torch.float64, generator=g)
+    theta = torch.cat([0.4 + torch.rand(T, D, dtype=torch.float64, generator=g), 0.5 + torch.rand(T, 1, dtype=torch.float64, generator=g),
+                       torch.full((T, 1), 2e-3, dtype=torch.float64)], 1)
+    xq = torch.rand(M, D, dtype=torch.float64, generator=g)
+    n = torch.tensor([N, max(N - 9, 1)] + [N] * (T - 2), dtype=torch.int32)
+    ym = torch.randn(T, dtype=torch.float64, generator=g)
+    ysd = 0.5 + torch.rand(T, dtype=torch.float64, generator=g)
+    fit = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, n_points=n.to(device), want_linv=True)
+    Linv = ops.linv_batched(fit["L"], fit["Linv_diag"], n_points=n.to(device))
+    args = (xq.to(device), X.to(device), theta.to(device), kind, fit["L"], fit["Linv_diag"], fit["alpha"], ym.to(device), ysd.to(device))
+    a = ops.source_posteriors(*args, n_points=n.to(device), cov_first=M, keep_V=True)
+    b = ops.source_posteriors(*args, n_points=n.to(device), cov_first=M, keep_V=True, Linv=Linv)
+    for k in ("mean", "var", "cov", "V"):
+        torch.testing.assert_close(b[k], a[k], rtol=1e-8, atol=1e-10)
+    for t in range(T):
+        k = int(n[t])
+        ref = O.gp_fit(X[t, :k], y[t, :k], theta[t], kind)
+        torch.testing.assert_close(torch.tril(Linv[t, :k, :k].cpu()), torch.linalg.inv(ref["L"]), rtol=1e-6, atol=1e-8)
+        mu, cov = O.source_posterior(xq, X[t, :k], theta[t], kind, ref["L"], ref["alpha"], float(ym[t]), float(ysd[t]))
+        torch.testing.assert_close(b["mean"][t].cpu(), mu, rtol=RTOL, atol=1e-7)
+        torch.testing.assert_close(b["cov"][t].cpu(), cov, rtol=RTOL, atol=1e-7)
+    # per-task query sets go through the same kernel
+    xqt = torch.rand(T, M, D, dtype=torch.float64, generator=g)
+    c = ops.source_posteriors(xqt.to(device), *args[1:], n_points=n.to(device))
+    d = ops.source_posteriors(xqt.to(device), *args[1:], n_points=n.to(device), Linv=Linv)
+    torch.testing.assert_close(d["mean"], c["mean"], rtol=1e-8, atol=1e-10)
+    torch.testing.assert_close(d["var"], c["var"], rtol=1e-8, atol=1e-10)
