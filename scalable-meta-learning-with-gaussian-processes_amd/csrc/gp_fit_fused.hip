@@ -93,18 +93,21 @@ __device__ __forceinline__ int opaque_s(int v) {
 // All waves of the workgroup are resident, so a spinning wave cannot starve the one it waits for;
 // s_sleep keeps the pollers off the issue ports.  Release/acquire at workgroup scope orders the LDS
 // traffic (on gfx950 that is s_waitcnt lgkmcnt(0) around the atomic; HBM stores are not waited for).
+#ifndef SCAML_SLEEP
+#define SCAML_SLEEP 1   // s_sleep argument of the pollers (64-cycle units); A/B-tuned
+#endif
 typedef __attribute__((address_space(3))) int lds_int_t;
 __device__ __forceinline__ int sync_peek(const int* p) {
   return __hip_atomic_load((const lds_int_t*)p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void sync_wait_ge(const int* p, int target) {
-  while (sync_peek(p) < target) __builtin_amdgcn_s_sleep(1);
+  while (sync_peek(p) < target) __builtin_amdgcn_s_sleep(SCAML_SLEEP);
 }
 // waiting side of a hand-off that may never come because the panel wave hit a bad pivot
 __device__ __forceinline__ bool sync_wait_ge_or_fail(const int* p, int target, const int* failp) {
   while (sync_peek(p) < target) {
     if (sync_peek(failp) != 0) return false;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SCAML_SLEEP);
   }
   return true;
 }
@@ -683,7 +686,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         // ---- F(c): column c becomes final
         {
           int fw;
-          while ((fw = sync_peek(flagW + c)) == 0) __builtin_amdgcn_s_sleep(1);
+          while ((fw = sync_peek(flagW + c)) == 0) __builtin_amdgcn_s_sleep(SCAML_SLEEP);
           STAMP_K(k, 4);
           STAMP(5);
           if (fw == 2) break;
