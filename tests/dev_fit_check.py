@@ -1,4 +1,5 @@
-"""Developer check: fused fit kernel vs the CPU oracle on a few shapes (needs a GPU)."""
+"""Developer check (a script, not collected by pytest): fused fit kernel vs the CPU oracle on a few shapes
+(needs a GPU).  It lives under tests/ because it uses the oracle, which only test code may import."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd"))
