@@ -130,12 +130,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    device = torch.device("cuda", local_rank)
+    # SCAML_BENCH_REHEARSAL=1: rehearse the multi-rank control flow on ONE GPU (all ranks on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device).  Numbers from such a run mean nothing; it exists so that the
+    # barrier / all-reduce / max-over-ranks logic can be exercised on a one-GPU box.
+    rehearsal = os.environ.get("SCAML_BENCH_REHEARSAL") == "1"
+    device = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(device)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     host_inputs, (X, y, th) = make_inputs(rank, device)
     kind = ops.KIND_MATERN52
