@@ -383,21 +383,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     if (tid == 0) flagp[0] = 0;
     if (tid < 6 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);
-    if (!is_panel && lane == 0) {
-      // which off-diagonal tiles of each block row this wave holds (for the back-substitution)
-      int* rl = rowlist + wave * NB * 8;
-      for (int i = 0; i < NB; ++i) rl[8 * i] = 0;
-      int j = 0, r = wave;
-      for (int s = 0; s < SLOTS; ++s) {
-        while (j < NB && r >= NB - j) { r -= NB - j; ++j; }
-        if (j >= NB) break;
-        if (r > 0) {
-          const int i = j + r, c = rl[8 * i];
-          if (c < 7) { rl[8 * i + 1 + c] = (s << 8) | j; rl[8 * i] = c + 1; }
-        }
-        r += WU;
-      }
-    }
     __syncthreads();
     // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
     for (int r = tid; r < NP; r += NTHREADS) {
@@ -612,6 +597,24 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         sync_publish(flagW + j, 1, lane);
         STAMP_AT(j);
         STAMP(9);
+        if (j == 1 && lane < WU) {
+          // Off the critical path (the chain waits for parked tiles next anyway): which off-diagonal tiles of
+          // each block row the update waves hold, for the back-substitution at the end -- lane w lists wave w.
+          int* rl = rowlist + lane * NB * 8;
+#pragma clang loop unroll(disable)
+          for (int i = 0; i < NB; ++i) rl[8 * i] = 0;
+          int jj = 0, r = lane;
+#pragma clang loop unroll(disable)
+          for (int sl = 0; sl < SLOTS; ++sl) {
+            while (jj < NB && r >= NB - jj) { r -= NB - jj; ++jj; }
+            if (jj >= NB) break;
+            if (r > 0) {
+              const int i = jj + r, c = rl[8 * i];
+              if (c < 7) { rl[8 * i + 1 + c] = (sl << 8) | jj; rl[8 * i] = c + 1; }
+            }
+            r += WU;
+          }
+        }
       }
       __builtin_amdgcn_s_setprio(0);
     } else {
