@@ -1,0 +1,45 @@
+"""GPU parity tests of the fused fit at the edges of its shape space: single points, one task, many small
+tasks (more workgroups than CUs), N off the 16-grid, empty and one-point ragged tasks, large D.
+Held to 1e-9 on L / MLL and 1e-6 on alpha against the oracle evaluated with the kernels' own distance
+formulation (north_star asks 1e-4 / 1e-3)."""
+import pytest
+import torch
+
+from oracle import gp_oracle as O
+from scamlgp_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (1, 16, 1, O.KIND_RBF, None),
+    (1, 1, 1, O.KIND_MATERN52, None),
+    (2, 17, 20, O.KIND_MATERN52, None),
+    (2, 256, 30, O.KIND_RBF, None),
+    (3, 255, 7, O.KIND_MATERN52, None),
+    (4, 64, 3, O.KIND_RBF, [0, 1, 64, 33]),
+    (2, 241, 2, O.KIND_MATERN52, [241, 240]),
+    (300, 48, 2, O.KIND_RBF, None),
+    (2, 129, 4, O.KIND_MATERN52, None),
+]
+
+
+@pytest.mark.parametrize("T,N,D,kind,npts", CASES)
+def test_fit_edge_shapes(T, N, D, kind, npts, device):
+    g = torch.Generator().manual_seed(1000 * N + D)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g)
+    y = torch.randn(T, N, dtype=torch.float64, generator=g)
+    theta = torch.cat([0.3 + torch.rand(T, D, dtype=torch.float64, generator=g) * D ** 0.5, torch.ones(T, 1, dtype=torch.float64),
+                       torch.full((T, 1), 1e-3, dtype=torch.float64)], 1)
+    n = None if npts is None else torch.tensor(npts, dtype=torch.int32)
+    out = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, n_points=None if n is None else n.to(device))
+    assert not out["info"].cpu().any()
+    for t in range(min(T, 12)):
+        k = N if n is None else int(n[t])
+        if k == 0:
+            continue
+        ref = O.gp_fit(X[t, :k], y[t, :k], theta[t], kind, dist="direct")
+        torch.testing.assert_close(out["L"][t, :k, :k].cpu(), ref["L"], rtol=1e-9, atol=1e-11)
+        torch.testing.assert_close(out["alpha"][t, :k].cpu(), ref["alpha"], rtol=1e-6, atol=1e-9)
+        torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-9, atol=1e-12)
+        if k < N:   # rows / columns past n_t are never written (the caller's zeros stay)
+            assert float(out["L"][t, k:, :].abs().sum()) == 0.0 and float(out["alpha"][t, k:].abs().sum()) == 0.0
