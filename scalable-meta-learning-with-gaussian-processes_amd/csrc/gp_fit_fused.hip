@@ -186,7 +186,10 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, d
     const double lcol = am * ri;   // L[lc][c]
     const double wrow = Rm * ri;   // W[c][lc]
     if (c < 15) {
+      // (the update of `a` is the one the next pivots wait for: it must enter the pipe first -- left alone,
+      //  the scheduler tends to issue the R update, whose operands are ready earlier, in front of it)
       a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
+      __builtin_amdgcn_sched_barrier(0);
       R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
     }
     baseL[g][c] = lcol;
