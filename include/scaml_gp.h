@@ -161,6 +161,15 @@ int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t
                                 int power, double* out, void* stream);
 
 /*
+ * (6') The ScaML-GP target prior of scamlgp/model.py:108-135 in one call, on the outputs of (5)/(5b):
+ *   mu_s[q] = sum_t w_t mu[t][q]  (mu (T, M)),   cov_s[a][q] = sum_t w_t^2 cov[t][a][q]  (cov (T, Ma, M)),
+ * over the tasks with active[t] != 0 (the pruning mask of model.py:368-372; NULL = all).  Either of mu / cov may
+ * be NULL.  Two launches of the weighted-sum kernel.
+ */
+int scaml_weighted_prior_reduce_f64(const double* mu, const double* cov, const double* w, const uint8_t* active, int T, int M,
+                                    int Ma, double* mu_s, double* cov_s, void* stream);
+
+/*
  * (4) Analytic gradient of mll[t] (as defined for scaml_gp_fit_fused_f64, no prior terms) w.r.t. the
  * constrained hyper-parameters theta[t] = [l_0..l_{D-1}, os, noise].  Replaces the autograd pass of
  * botorch's fit_gpytorch_mll through kernel, Cholesky and solve (scamlgp/utils.py:175, 190).

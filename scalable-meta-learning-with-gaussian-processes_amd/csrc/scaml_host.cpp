@@ -290,6 +290,17 @@ int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const 
   return SCAML_OK;
 }
 
+// the weighted target prior in one call: mean with w, covariance with w^2 (two launches of the sum kernel)
+int scaml_weighted_prior_reduce_f64(const double* mu, const double* cov, const double* w, const uint8_t* active, int T, int M,
+                                    int Ma, double* mu_s, double* cov_s, void* stream) {
+  if (T < 0 || M < 0 || Ma < 0) return SCAML_E_BADARG;
+  if (!w || (mu && !mu_s) || (cov && !cov_s) || (!mu && !cov)) return SCAML_E_BADARG;
+  int rc = SCAML_OK;
+  if (mu) rc = scaml_weighted_task_sum_f64(mu, w, active, T, (long long)M, 1, mu_s, stream);
+  if (rc == SCAML_OK && cov) rc = scaml_weighted_task_sum_f64(cov, w, active, T, (long long)Ma * M, 2, cov_s, stream);
+  return rc;
+}
+
 // ---- explicit inverse factor + posteriors from it -------------------------------------------------
 static int launch_linv(Module& m, const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N,
                        double* Linv, void* stream) {

@@ -88,6 +88,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_cho_solve_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, c_void_p]
     lib.scaml_weighted_task_sum_f64.restype = c_int
     lib.scaml_weighted_task_sum_f64.argtypes = [_dp, _dp, _dp, c_int, ctypes.c_longlong, c_int, _dp, c_void_p]
+    lib.scaml_weighted_prior_reduce_f64.restype = c_int
+    lib.scaml_weighted_prior_reduce_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, _dp, c_void_p]
     lib.scaml_mll_backward_workspace_doubles.restype = ctypes.c_longlong
     lib.scaml_mll_backward_workspace_doubles.argtypes = [c_int, c_int, c_int]
     lib.scaml_mll_backward_f64.restype = c_int
@@ -113,6 +115,7 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_linv_f64",
     "scaml_cho_solve_batched_f64",
     "scaml_weighted_task_sum_f64",
+    "scaml_weighted_prior_reduce_f64",
     "scaml_mll_backward_workspace_doubles",
     "scaml_mll_backward_f64",
 )

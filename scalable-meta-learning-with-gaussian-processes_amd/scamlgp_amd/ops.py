@@ -362,6 +362,30 @@ def weighted_task_sum(values: torch.Tensor, weights: torch.Tensor, power: int = 
     return out
 
 
+def weighted_prior_reduce(mu: Optional[torch.Tensor], cov: Optional[torch.Tensor], weights: torch.Tensor,
+                          active: Optional[torch.Tensor] = None):
+    """Target prior of scamlgp/model.py:108-135 from stacked source posteriors: (sum_t w_t mu[t], sum_t w_t^2 cov[t])
+    over the active tasks.  mu (T, M), cov (T, Ma, M); either may be None.  scaml_weighted_prior_reduce_f64."""
+    T = weights.shape[0]
+    weights = _check(weights, "weights", (T,))
+    M = mu.shape[1] if mu is not None else cov.shape[2]
+    Ma = cov.shape[1] if cov is not None else 0
+    if mu is not None:
+        mu = _check(mu, "mu", (T, M))
+    if cov is not None:
+        cov = _check(cov, "cov", (T, Ma, M))
+    if active is not None:
+        active = active.to(torch.uint8).contiguous()
+    dev = weights.device
+    mu_s = torch.empty((M,), dtype=torch.float64, device=dev) if mu is not None else None
+    cov_s = torch.empty((Ma, M), dtype=torch.float64, device=dev) if cov is not None else None
+    with torch.cuda.device(dev):
+        rc = _lib.lib.scaml_weighted_prior_reduce_f64(_ptr(mu), _ptr(cov), _ptr(weights), _ptr(active), T, M, Ma, _ptr(mu_s),
+                                                      _ptr(cov_s), _stream_handle())
+    _lib.check_rc(rc, "scaml_weighted_prior_reduce_f64")
+    return mu_s, cov_s
+
+
 def mll_backward(
     X: torch.Tensor,
     theta: torch.Tensor,

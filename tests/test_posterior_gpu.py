@@ -134,3 +134,19 @@ def test_posterior_from_explicit_inverse_matches_substitution_and_oracle(T, N, D
     d = ops.source_posteriors(xqt.to(device), *args[1:], n_points=n.to(device), Linv=Linv)
     torch.testing.assert_close(d["mean"], c["mean"], rtol=1e-8, atol=1e-10)
     torch.testing.assert_close(d["var"], c["var"], rtol=1e-8, atol=1e-10)
+
+
+def test_weighted_prior_reduce_matches_oracle(device):
+    g = torch.Generator().manual_seed(4)
+    T, M, Ma = 7, 19, 5
+    mu = torch.randn(T, M, dtype=torch.float64, generator=g)
+    cov = torch.randn(T, Ma, M, dtype=torch.float64, generator=g)
+    w = torch.rand(T, dtype=torch.float64, generator=g)
+    active = torch.tensor([1, 1, 0, 1, 0, 1, 1], dtype=torch.bool)
+    mu_s, cov_s = ops.weighted_prior_reduce(mu.to(device), cov.to(device), w.to(device), active.to(device))
+    wa = w * active
+    torch.testing.assert_close(mu_s.cpu(), (wa[:, None] * mu).sum(0), rtol=1e-12, atol=1e-14)
+    torch.testing.assert_close(cov_s.cpu(), ((wa ** 2)[:, None, None] * cov).sum(0), rtol=1e-12, atol=1e-14)
+    mu_only, none = ops.weighted_prior_reduce(mu.to(device), None, w.to(device))
+    assert none is None
+    torch.testing.assert_close(mu_only.cpu(), (w[:, None] * mu).sum(0), rtol=1e-12, atol=1e-14)
