@@ -568,8 +568,31 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         if (j >= 2) sync_wait_ge(cntS + j - 2, WU);
         STAMP(3);
         // (cntS[j-2] complete: column j-2 is final in its LDS buffer, which F(j) reuses after flagW[j])
-        if (Lg && j >= 2 && j - 2 < PSTORE)
-          for (int ti = j - 1; ti < NB; ++ti) store_tile(j - 2, ti);
+        if (Lg && j >= 2 && j - 2 < PSTORE) {
+          // (SCAML_STRIP tiles per trip: their LDS reads are issued together, one exposed latency for all)
+#ifndef SCAML_STRIP
+#define SCAML_STRIP 4
+#endif
+          const int c = j - 2;
+          int ti = j - 1;
+          for (; ti + SCAML_STRIP - 1 < NB && 16 * (ti + SCAML_STRIP) <= n; ti += SCAML_STRIP) {
+            const double* prow = PT + (c & 1) * PANEL + (16 * ti + lq) * PP + lc;
+            double e[4 * SCAML_STRIP];
+#pragma unroll
+            for (int u = 0; u < 4 * SCAML_STRIP; ++u) e[u] = prow[4 * u * PP];
+            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c) + lane_idx;
+#pragma unroll
+            for (int u = 0; u < 4 * SCAML_STRIP; ++u) tb[(size_t)4 * u * N] = e[u];
+            if (zero_upper) {
+              double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti) + lane_idx;
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < SCAML_STRIP; ++u) mb[(size_t)g * 4 * N + 16 * u] = 0.0;
+            }
+          }
+          for (; ti < NB; ++ti) store_tile(c, ti);
+        }
         d4_t a;
         {
           const double* dg = DG + (j & 1) * 256 + lane;   // symmetric: the transposed image is the block
