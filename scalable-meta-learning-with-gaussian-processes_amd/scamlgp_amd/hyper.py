@@ -97,9 +97,15 @@ class HyperSpec:
         return [self.ls_prior] * D + [self.os_prior, self.noise_prior]
 
     def bounds(self, D: int, dtype=torch.float64, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
-        lo = torch.tensor([c.lower for c in self.constraints(D)], dtype=dtype, device=device)
-        hi = torch.tensor([c.upper for c in self.constraints(D)], dtype=dtype, device=device)
-        return lo, hi
+        # memoised per (D, dtype, device): building device tensors from Python lists is a synchronous host-to-device
+        # copy, and this is called several times per objective evaluation of the batched optimiser
+        key = (D, dtype, str(device), tuple((c.lower, c.upper) for c in (self.ls_constraint, self.os_constraint, self.noise_constraint)))
+        cache = self.__dict__.setdefault("_bounds_cache", {})
+        if key not in cache:
+            lo = torch.tensor([c.lower for c in self.constraints(D)], dtype=dtype, device=device)
+            hi = torch.tensor([c.upper for c in self.constraints(D)], dtype=dtype, device=device)
+            cache[key] = (lo, hi)
+        return cache[key]
 
     def init_theta(self, D: int, dtype=torch.float64, device=None) -> torch.Tensor:
         return torch.tensor([self.ls_init] * D + [self.os_init, self.noise_init], dtype=dtype, device=device)
