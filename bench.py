@@ -192,7 +192,7 @@ def main():
         flops = algorithmic_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         res = {
-            "metric": "task-posteriors/sec (K+chol+solve+MLL) at T=256,N=256",
+            "metric": "task-posteriors/sec (K+chol+solve+MLL) at T=256,N=256; 1/2/4/8 GPU",
             "value": world * T_PER_GPU * args.steps / elapsed,
             "unit": "task-posteriors/s",
             "n_gpus": world,
