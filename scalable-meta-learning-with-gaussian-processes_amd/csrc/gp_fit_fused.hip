@@ -330,7 +330,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* LT = CR + 2 * 256;
   constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
   // (during the build: xsT, then up to 24 tile images written by the panel wave, see PANEL_BUILDS)
-  const int buildA = p.D * NP + 2 + 24 * 256;
+  const int buildA = p.D * NP + 2 + ((WU == 7 && NB == 16) ? 24 * 256 : 0);
   const int regionA = (buildA > REGION_A) ? buildA : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
@@ -967,6 +967,6 @@ __global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p
   template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 0>(scaml::FitParams); \
   template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 1>(scaml::FitParams);
 SCAML_INSTANTIATE(2, 1)
-SCAML_INSTANTIATE(4, 1)
+SCAML_INSTANTIATE(4, 3)
 SCAML_INSTANTIATE(8, 3)
 SCAML_INSTANTIATE(16, 7)

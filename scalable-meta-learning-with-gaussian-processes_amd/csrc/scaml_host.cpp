@@ -38,7 +38,7 @@ struct Module {
   std::mutex mu;
   bool loaded = false;
   hipModule_t mod = nullptr;
-  FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 1, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
+  FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 3, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t post_linv[2] = {nullptr, nullptr};
@@ -99,7 +99,7 @@ Module& module() {
 size_t fit_lds_bytes(int nb, int wu, int D) {
   const int np = nb * 16;
   size_t regionA = (size_t)2 * np * PP + (size_t)(nb + 2) * 16 * PP + 4 * 256;   // PT[2], WAll[nb], LT[2], DG[2], CR[2]
-  const size_t buildA = (size_t)D * np + 2 + 24 * 256;   // X/l transposed + the panel wave's tile images
+  const size_t buildA = (size_t)D * np + 2 + (nb == 16 ? 24 * 256 : 0);   // X/l transposed + the panel wave's tile images (N > 128 only)
   if (buildA > regionA) regionA = buildA;
   // + vectors, trash/exp table, row lists, 1/l, fail flag + 6 nb hand-off counters (ints)
   return (regionA + 4 * np + 160 + (size_t)wu * nb * 4 + (size_t)wu * 16 + D + (D & 1) + 2 + 3 * (size_t)nb) * sizeof(double);
