@@ -38,9 +38,9 @@ def algorithmic_flops_per_task(N: int, D: int, matern: bool) -> float:
 
 
 def algorithmic_bytes_per_task(N: int, D: int) -> float:
-    """Read X, y, theta; write the lower triangle of L (the zero upper triangle of the resident output
-    buffer is written once, outside the timed steps), alpha, 3 scalars, info, jitter."""
-    return 8.0 * (N * D + N + D + 2) + 8.0 * (N * (N + 1) / 2 + N + 3) + 4 + 8
+    """SURVEY.md §8(d), "L stored (full)": read X, y, theta; write the dense N x N factor (zeros above the
+    diagonal included, every step), alpha, 3 scalars, info, jitter."""
+    return 8.0 * (N * D + N + D + 2) + 8.0 * (N * N + N + 3) + 4 + 8
 
 
 def recorded_pmc_traffic():
@@ -146,15 +146,14 @@ def main():
 
     host_inputs, (X, y, th) = make_inputs(rank, device)
     kind = ops.KIND_MATERN52
-    # allocates the output buffers once; this first call also writes the zero upper triangle of L, the
-    # timed steps then rewrite only the lower triangle into the same resident buffer (it stays zero above)
+    # allocates the output buffers once; every step rewrites them completely
     out = ops.gp_fit_fused(X, y, th, kind)
     total = args.warmup + args.steps
     sums = torch.zeros(total, 1, dtype=torch.float64, device=device)
     works = []
 
     def step(i):
-        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=False)
+        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=True)   # the full dense L, zeros included, every step
         if distributed:
             torch.sum(out["mll"], dim=0, keepdim=True, out=sums[i])
             works.append(dist.all_reduce(sums[i], async_op=True))
