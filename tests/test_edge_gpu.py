@@ -43,3 +43,21 @@ def test_fit_edge_shapes(T, N, D, kind, npts, device):
         torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-9, atol=1e-12)
         if k < N:   # rows / columns past n_t are never written (the caller's zeros stay)
             assert float(out["L"][t, k:, :].abs().sum()) == 0.0 and float(out["alpha"][t, k:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("ls,noise,kind", [(1.0, 1e-6, O.KIND_MATERN52), (1.0, 1e-6, O.KIND_RBF), (2.0, 1e-8, O.KIND_RBF)])
+def test_fit_conditioning_stress(ls, noise, kind, device):
+    """"for a conditioning stress, l = 1.0, sigma^2 = 1e-6" (and harsher).  Against the oracle in the
+    reference's own (gpytorch-style) distance formulation; north_star tolerances 1e-4 on alpha, 1e-3 on the MLL."""
+    from scamlgp_amd import synthetic
+    T, N, D = 4, 256, 8
+    d = synthetic.smooth_field_task_stack(T, N, D, seed=3)
+    ys, _, _ = synthetic.standardize_rows(d["Y"])
+    X, y = torch.from_numpy(d["X"]), torch.from_numpy(ys)
+    theta = torch.cat([torch.full((T, D), ls), torch.ones(T, 1), torch.full((T, 1), noise)], 1).double()
+    out = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind)
+    ref = O.gp_fit_stack_loop(X, y, theta, kind, dist="gpytorch")
+    assert not out["info"].cpu().any() and out["jitter"].cpu().tolist() == ref["jitter"].tolist()
+    torch.testing.assert_close(out["alpha"].cpu(), ref["alpha"], rtol=1e-4, atol=1e-4 * float(ref["alpha"].abs().max()))
+    torch.testing.assert_close(out["mll"].cpu(), ref["mll"], rtol=1e-3, atol=0)
+    torch.testing.assert_close(out["L"].cpu(), ref["L"], rtol=1e-6, atol=1e-9)
