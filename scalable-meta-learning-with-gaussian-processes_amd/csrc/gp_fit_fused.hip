@@ -330,7 +330,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   double* LT = CR + 2 * 256;
   constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
   // (during the build: xsT, then up to 24 tile images written by the panel wave, see PANEL_BUILDS)
-  const int buildA = p.D * NP + 2 + ((WU == 7 && NB == 16) ? 24 * 256 : 0);
+  const int XROWS = ((p.D + 3) & ~3) + 4;   // staged point stack: D rounded up to the MFMA k-step + 4 tail rows
+  const int buildA = XROWS * NP + ((WU == 7 && NB == 16) ? 24 * 256 : 0);
   const int regionA = (buildA > REGION_A) ? buildA : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
@@ -380,21 +381,44 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   STAMP_DECL;
   int fail = 0;
   {
-    const double diag_add = noise + jitter + jit_in;
     __syncthreads();  // previous attempt done with region A
-    if (!from_matrix && tid < D) invl[tid] = 1.0 / th[tid];
-    if (tid == 0) flagp[0] = 0;
+    // (sqrt 2 folded into the scaling: the cross term of the squared distance then needs no factor 2)
+    if (!from_matrix && tid < D) invl[tid] = 1.4142135623730951 / th[tid];
+    if (tid < 2) flagp[tid] = 0;
     if (tid < 6 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);
     __syncthreads();
-    // ---- stage X / l transposed into LDS: xsT[d][row]; y into ytil
+    // ---- stage x' = sqrt(2) X / l transposed into LDS: xsT[d][row], rows D .. D4-1 zero, then the tail rows
+    // (-|x'|^2 / 2, 1, 0, 0): with them the squared distance is ONE chain of MFMAs,
+    //   d2(a, b) = -(x'_a . x'_b + h_a * 1 + 1 * h_b),  h = -|x'|^2 / 2
+    // (the expansion gpytorch's sq_dist uses, model.py:44-70 -> RBFKernel / MaternKernel), instead of 2 D VALU
+    // operations per matrix element.  y into ytil.
+    const int D4 = (D + 3) & ~3;
     for (int r = tid; r < NP; r += NTHREADS) {
       const bool in = r < n;
-      if (!from_matrix)
-        for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+      if (!from_matrix) {
+        double h = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double v = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+          xsT[d * NP + r] = v;
+          h = __builtin_fma(v, v, h);
+        }
+        for (int d = D; d < D4; ++d) xsT[d * NP + r] = 0.0;
+        h *= -0.5;
+        xsT[D4 * NP + r] = h;
+        xsT[(D4 + 1) * NP + r] = 1.0;
+        xsT[(D4 + 2) * NP + r] = 0.0;
+        xsT[(D4 + 3) * NP + r] = 0.0;
+        // NaN / inf points or lengthscales: the clamps of the kernel function would swallow a NaN, so the
+        // diagonal is poisoned instead and the factorisation fails the way psd_safe_cholesky fails on NaN
+        if (!(__builtin_fabs(h) <= 1e300)) flagp[1] = 1;
+      }
       ytil[r] = (in && yg) ? yg[r] : 0.0;
     }
     __syncthreads();
+    const double diag_add = noise + jitter + jit_in + (flagp[1] ? __builtin_nan("") : 0.0);
+    // outputscale folded into the polynomial of the Matern kernel (RBF: c0 only)
+    const double kc0 = os, kc1 = os * 2.2360679774997896964, kc2 = os * (5.0 / 3.0);
     STAMP(0);
 
     // ---- kernel matrix straight into the accumulator tiles
@@ -414,27 +438,27 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           kt[g] = kv;
         }
       } else {
-        double d2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-        for (int d = 0; d < D; ++d) {
-          const double* xr = xsT + d * NP;
-          const double xc = xr[row];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            double df = xr[col0 + 4 * g] - xc;
-            d2[g] = __builtin_fma(df, df, d2[g]);
-          }
+        // squared distances of the whole tile on the matrix core: A = points of block column kj (the MFMA's
+        // row index is the tile's column, tiles are held transposed), B = points of block row kj + kr,
+        // A negated by the instruction (blgp = 1)
+        d4_t d2 = {0.0, 0.0, 0.0, 0.0};
+        {
+          const double* pa = xsT + lq * NP + 16 * kj + lc;
+          const double* pb = xsT + lq * NP + 16 * (kj + kr) + lc;
+          for (int m = 0; m < D4; m += 4) d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[m * NP], pb[m * NP], d2, 0, 0, 1);
+          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xsT[(D4 + lq) * NP + 16 * kj + lc], xsT[(D4 + (lq ^ 1)) * NP + 16 * (kj + kr) + lc],
+                                                    d2, 0, 0, 1);
         }
         // wave-uniform fast path: an off-diagonal tile entirely inside the n valid points needs neither the
         // diagonal term nor the identity padding (saves ~10 VALU instructions per element)
         if (kr != 0 && 16 * (kj + kr) + 16 <= n) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) kt[g] = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+          for (int g = 0; g < 4; ++g) kt[g] = kernel_from_sqdist_scaled<KIND>(d2[g], kc0, kc1, kc2, exptab);
         } else {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int col = col0 + 4 * g;
-            double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
+            double kv = kernel_from_sqdist_scaled<KIND>(row == col ? 0.0 : d2[g], kc0, kc1, kc2, exptab);
             if (row == col) kv += diag_add;
             if (row >= n || col >= n) kv = row == col ? 1.0 : 0.0;
             kt[g] = kv;
@@ -455,7 +479,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #define SCAML_KYOUNG 16
 #endif
     auto kslot_of = [](int w) { return w < KMATE ? SCAML_KOLD : SCAML_KYOUNG; };
-    double* KT = lds + ((D * NP + 1) & ~1);   // [6][4][256] register images, behind xsT
+    double* KT = lds + XROWS * NP;   // [6][4][256] register images, behind xsT
     if (!is_panel) {
       int kj = 0, kr = wave;  // column / row-in-column of the current slot's tile
 #define SCAML_KBUILD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \

@@ -89,6 +89,47 @@ __device__ __forceinline__ double kernel_from_sqdist(double d2, const double* ex
   }
 }
 
+// The fused fit's variant: d2 comes off the matrix core (expanded form, may be slightly negative, never NaN --
+// non-finite inputs are caught when the points are staged), the outputscale is folded into the polynomial
+// (c0 = os, c1 = sqrt(5) os, c2 = 5/3 os), and r = d2 * rsqrt(d2) without the correction step (<= 1.5 ulp).
+// d2 is clamped to [1e-30, 1e5]: k(1e5) ~ 1e-302 os, and -sqrt(5) r stays inside the range exp_neg handles
+// without its own clamp.  Bare v_max / v_min: the builtins add a canonicalising v_max in front.
+__device__ __forceinline__ double vmax_f64(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin_f64(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+  return r;
+}
+template <bool CLAMP>
+__device__ __forceinline__ double exp_neg_t(double x, const double* tab) {
+  if (CLAMP) x = vmax_f64(x, -746.0);
+  const double nf = __builtin_rint(x * 92.332482616893656877);     // 64 / ln 2
+  double r = __builtin_fma(nf, -0x1.62e42fee00000p-7, x);
+  r = __builtin_fma(nf, -0x1.a39ef35793c76p-39, r);
+  const int n = (int)nf;
+  const double t = tab[n & 63];
+  double p = __builtin_fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p * r, r, r);
+  return __builtin_ldexp(__builtin_fma(t, p, t), n >> 6);
+}
+template <int KIND>
+__device__ __forceinline__ double kernel_from_sqdist_scaled(double d2, double c0, double c1, double c2, const double* exp_tab) {
+  if (KIND == 0) {  // RBF: os exp(-d2/2)
+    return c0 * exp_neg_t<true>(-0.5 * d2, exp_tab);
+  } else {
+    const double dd = vmin_f64(vmax_f64(d2, 1e-30), 1e5);
+    const double r = dd * rsqrt_seeded(dd);
+    const double poly = __builtin_fma(__builtin_fma(r, c2, c1), r, c0);
+    return poly * exp_neg_t<false>(-2.2360679774997896964 * r, exp_tab);
+  }
+}
+
 // x summed over the four lane groups lq (lanes l, l^16, l^32, l^48), result in every lane: gfx950's
 // v_permlane{32,16}_swap exchange half-waves / odd-even rows in one VALU op per dword (no LDS crossbar)
 __device__ __forceinline__ double sum_lane_groups(double x) {
