@@ -424,7 +424,40 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     // ---- kernel matrix straight into the accumulator tiles
     // One 16x16 tile (block row kj + kr, block column kj), the four values of this lane (transposed tile:
     // the lane owns a row piece).
-    auto build_tile = [&](int kj, int kr, double (&kt)[4]) {
+    // squared distances of one whole tile on the matrix core: A = points of block column kj (the MFMA's row
+    // index is the tile's column, tiles are held transposed), B = points of block row kj + kr, A negated by
+    // the instruction (blgp = 1).  The operand reads run one MFMA ahead.
+    auto tile_dist = [&](int kj, int kr) -> d4_t {
+      // (also run when the matrix is given -- on whatever the LDS holds, result unused: a conditional here
+      //  becomes a select on the MFMA result right behind the MFMA, see tile_eval)
+      d4_t d2 = {0.0, 0.0, 0.0, 0.0};
+      const double* pa = xsT + lq * NP + 16 * kj + lc;
+      const double* pb = xsT + lq * NP + 16 * (kj + kr) + lc;
+      const double ta = xsT[(D4 + lq) * NP + 16 * kj + lc], tb = xsT[(D4 + (lq ^ 1)) * NP + 16 * (kj + kr) + lc];
+      double ca = pa[0], cb = pb[0];
+      for (int m = 4; m < D4; m += 4) {
+        const double na = pa[m * NP], nb = pb[m * NP];
+        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb, d2, 0, 0, 1);
+        ca = na; cb = nb;
+      }
+      d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ca, cb, d2, 0, 0, 1);
+      d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, tb, d2, 0, 0, 1);
+      return d2;
+    };
+    // One 16x16 tile (block row kj + kr, block column kj), the four values of this lane (transposed tile:
+    // the lane owns a row piece), from its squared distances.
+    auto tile_eval = [&](int kj, int kr, d4_t d2, double (&kt)[4]) {
+      {
+        // gfx950: a VALU read of the first three result pairs of an fp64 MFMA is interlocked (it stalls until the
+        // MFMA is done), a read of the LAST pair is not -- and hipcc's wait states are those of the 8-pass gfx942
+        // instruction: a loop-carried copy of d2 once read stale registers (tools/mfma_hazard_probe.hip,
+        // profiles/r01_notes.md).  So the first pair is touched here before anything may read the rest;
+        // tools/mfma_hazard_audit.py checks the compiled code object, __graft_entry__.build() refuses a bad one.
+        double first = d2[0];
+        asm volatile("v_max_f64 %0, %0, %0" : "+v"(first));
+        d2[0] = first;
+        asm volatile("" : "+v"(d2));
+      }
       const int row = 16 * (kj + kr) + lc;
       const int col0 = 16 * kj + lq;
       if (from_matrix) {
@@ -438,17 +471,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           kt[g] = kv;
         }
       } else {
-        // squared distances of the whole tile on the matrix core: A = points of block column kj (the MFMA's
-        // row index is the tile's column, tiles are held transposed), B = points of block row kj + kr,
-        // A negated by the instruction (blgp = 1)
-        d4_t d2 = {0.0, 0.0, 0.0, 0.0};
-        {
-          const double* pa = xsT + lq * NP + 16 * kj + lc;
-          const double* pb = xsT + lq * NP + 16 * (kj + kr) + lc;
-          for (int m = 0; m < D4; m += 4) d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[m * NP], pb[m * NP], d2, 0, 0, 1);
-          d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xsT[(D4 + lq) * NP + 16 * kj + lc], xsT[(D4 + (lq ^ 1)) * NP + 16 * (kj + kr) + lc],
-                                                    d2, 0, 0, 1);
-        }
         // wave-uniform fast path: an off-diagonal tile entirely inside the n valid points needs neither the
         // diagonal term nor the identity padding (saves ~10 VALU instructions per element)
         if (kr != 0 && 16 * (kj + kr) + 16 <= n) {
@@ -482,12 +504,14 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     double* KT = lds + XROWS * NP;   // [6][4][256] register images, behind xsT
     if (!is_panel) {
       int kj = 0, kr = wave;  // column / row-in-column of the current slot's tile
+      // (issuing the distances of the next tile ahead of the evaluation of this one was tried: no gain, the
+      //  MFMA chain is short against the ~120 VALU instructions of the evaluation)
 #define SCAML_KBUILD_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                           \
       if (S < SLOTS && !(PANEL_BUILDS && wave != KMATE && S >= kslot_of(wave))) {                  \
         while (kj < NB && kr >= NB - kj) { kr -= NB - kj; ++kj; }                                  \
         if (kj < NB) {                                                                             \
           double kt[4];                                                                            \
-          build_tile(kj, kr, kt);                                                                  \
+          tile_eval(kj, kr, tile_dist(kj, kr), kt);                                                \
           TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, kt[0], kt[1], kt[2], kt[3]);                    \
           kr += WU;                                                                                \
         }                                                                                          \
@@ -496,13 +520,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #undef SCAML_KBUILD_
     } else if (PANEL_BUILDS) {
       for (int idx = 0; idx < 6 * 4; ++idx) {
-        const int w6 = idx >> 2, w = w6 + (w6 >= KMATE), s = kslot_of(w) + (idx & 3);
-        const int t = s * WU + w;
-        if (s >= SLOTS || t >= NT) continue;
+        const int w6 = idx >> 2, w = w6 + (w6 >= KMATE), sl = kslot_of(w) + (idx & 3);
+        const int t = sl * WU + w;
+        if (sl >= SLOTS || t >= NT) continue;
         int kj = 0, kr = t;
         while (kr >= NB - kj) { kr -= NB - kj; ++kj; }
         double kt[4];
-        build_tile(kj, kr, kt);
+        tile_eval(kj, kr, tile_dist(kj, kr), kt);
         double* img = KT + idx * 256 + lane;
         img[0] = kt[0]; img[64] = kt[1]; img[128] = kt[2]; img[192] = kt[3];
       }

@@ -107,10 +107,12 @@ __device__ __forceinline__ double vmin_f64(double a, double b) {
 template <bool CLAMP>
 __device__ __forceinline__ double exp_neg_t(double x, const double* tab) {
   if (CLAMP) x = vmax_f64(x, -746.0);
-  const double nf = __builtin_rint(x * 92.332482616893656877);     // 64 / ln 2
+  // n = rint(x * 64 / ln 2) by the 1.5 * 2^52 trick (|n| < 2^31 here): the integer sits in the low word of the sum
+  const double sh = __builtin_fma(x, 92.332482616893656877, 0x1.8p52);
+  const int n = __double2loint(sh);
+  const double nf = sh - 0x1.8p52;
   double r = __builtin_fma(nf, -0x1.62e42fee00000p-7, x);
   r = __builtin_fma(nf, -0x1.a39ef35793c76p-39, r);
-  const int n = (int)nf;
   const double t = tab[n & 63];
   double p = __builtin_fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
   p = __builtin_fma(p, r, 1.6666666666666666e-01);
@@ -124,7 +126,11 @@ __device__ __forceinline__ double kernel_from_sqdist_scaled(double d2, double c0
     return c0 * exp_neg_t<true>(-0.5 * d2, exp_tab);
   } else {
     const double dd = vmin_f64(vmax_f64(d2, 1e-30), 1e5);
-    const double r = dd * rsqrt_seeded(dd);
+    // r = sqrt(dd) straight from the f32 seed y ~ 1/sqrt(dd): g = dd y, e = 1 - g y, r = g (1 + e/2 + 3 e^2/8)
+    const double y = (double)__builtin_amdgcn_rsqf((float)dd);
+    const double g = dd * y;
+    const double e = __builtin_fma(-g, y, 1.0);
+    const double r = __builtin_fma(g * e, __builtin_fma(e, 0.375, 0.5), g);
     const double poly = __builtin_fma(__builtin_fma(r, c2, c1), r, c0);
     return poly * exp_neg_t<false>(-2.2360679774997896964 * r, exp_tab);
   }

@@ -22,6 +22,9 @@ q, ld, mll, jit = (torch.empty(T, dtype=torch.float64, device=dev) for _ in rang
 def run(l, flags):
     rc = l.scaml_gp_fit_fused_f64(X.data_ptr(), y.data_ptr(), th.data_ptr(), None, None, T, N, D, 1, L.data_ptr(), alpha.data_ptr(), q.data_ptr(), ld.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(), None, flags, None)
     assert rc == 0
+for n, l in libs.items():   # sanity line per build: a wrong kernel shows up as failed pivots / a different MLL sum
+    run(l, 1); torch.cuda.synchronize()
+    print(f"{n:28s} failed tasks {int((info != 0).sum())}  sum(mll) {float(mll.sum()):.12f}  max jitter {float(jit.max()):.1e}")
 res = {(n, f): [] for n in libs for f in (1, 3)}
 for rnd in range(8):
     for n, l in libs.items():
