@@ -59,10 +59,12 @@ __device__ __forceinline__ void exp2_table_init(double* tab, int tid) {
 
 __device__ __forceinline__ double exp_neg(double x, const double* tab) {
   x = __builtin_fmax(x, -746.0);   // (a NaN becomes -746 -> 0, as the select did)
-  const double nf = __builtin_rint(x * 92.332482616893656877);     // 64 / ln 2
+  // n = rint(x * 64 / ln 2) by the 1.5 * 2^52 trick (|n| < 2^31 here): the integer sits in the low word of the sum
+  const double sh = __builtin_fma(x, 92.332482616893656877, 0x1.8p52);
+  const int n = __double2loint(sh);
+  const double nf = sh - 0x1.8p52;
   double r = __builtin_fma(nf, -0x1.62e42fee00000p-7, x);   // ln2/64, high part (21 trailing zero bits: nf * hi is exact)
   r = __builtin_fma(nf, -0x1.a39ef35793c76p-39, r);          // ln2/64, low part
-  const int n = (int)nf;
   const double t = tab[n & 63];
   double p = __builtin_fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);
   p = __builtin_fma(p, r, 1.6666666666666666e-01);
