@@ -158,48 +158,55 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, d
     baseL[g] = (lds_double_t*)((lq == g) ? LT + lc * PP : trash + lane);
     baseW[g] = (lds_double_t*)((lq == g) ? Wt + lc * PP : trash + lane);
   }
-  // Pivot chain per step: rsqrt(dpiv) -> ri^2 -> next dpiv.  Everything else hangs off it: the raw
-  // row values are masked and read across lanes as soon as the previous MFMA lands (before ri is
-  // known), the range check is one running minimum, the two MFMAs and the LDS stores trail behind.
-  lds_double_t* pivlog = (lds_double_t*)(trash + 80);   // [16] the pivots, looked at only after a failure
-  double dmin = __builtin_inf();
-  double dpiv = readlane_f64(a[0], 0);
+  // A wave issues one VALU instruction per ~8.5 cycles whatever it is (tools/valu_rate_probe.hip) and executes
+  // in order, so a step costs its instruction count plus its stalls (stand-alone, tools/potf2_probe.hip: ~290
+  // cycles per pivot, of which ~150 are the floor MFMA -> read pivot -> scale column -> MFMA, ~60 the
+  // inverse's MFMA -- the matrix pipe takes one fp64 MFMA per 64 cycles -- and ~50 the rsqrt):
+  // * the pivot is read out of the accumulator once the previous rank-1 update has landed, rather than formed
+  //   ahead of the MFMA from the un-updated values (5 instructions more per step);
+  // * the MFMAs are asm, so that hipcc adds no wait states of its own behind them (it pads every read of the
+  //   result to 11-15 wait states; the hardware interlock on the first three result pairs stalls exactly as
+  //   long as needed);
+  // * no pivot log, no running minimum: a non-positive, NaN or f32-underflowing pivot makes the f32-seeded
+  //   rsqrt return NaN, which reaches every later column (0 * NaN), so the last diagonal entry tells whether
+  //   anything failed, and the first NaN on the stored diagonal of L tells where.
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int g = c & 3, rg = c >> 2;
     const bool mine = lq == g;
     const bool low = (unsigned)(lane - (16 * g + c)) < (unsigned)(16 - c);  // mine && lc >= c
-    const double am = low ? a[rg] : 0.0;    // raw column c (row c of the symmetric block), masked
-    const double Rm = mine ? R[rg] : 0.0;
-    // non-positive, NaN (or too small for the f32-seeded rsqrt): a NaN pivot poisons every later one, so
-    // the running minimum plus the last pivot tell whether anything failed; the index of the first
-    // failing step is only worked out then.  The garbage a failed step produces is never used.
-    pivlog[c] = dpiv;
-    dmin = __builtin_fmin(dmin, dpiv);
-    const double ri = rsqrt_seeded(dpiv);
-    if (c < 15) {
-      const int g1 = (c + 1) & 3, rg1 = (c + 1) >> 2;
-      const double acn = readlane_f64(a[rg], 16 * g + c + 1);      // a[c+1][c] before scaling
-      const double anext = readlane_f64(a[rg1], 16 * g1 + c + 1);  // a[c+1][c+1]
-      dpiv = __builtin_fma(-(acn * acn), ri * ri, anext);
+    if (rg == 3) {
+      // gfx950: reads of the LAST result pair of an fp64 MFMA are not interlocked -- touch the first pair of
+      // both accumulators before the steps that work on the last one (tools/mfma_hazard_probe.hip)
+      double a0 = a[0], r0 = R[0];
+      asm volatile("v_max_f64 %0, %0, %0\n\tv_max_f64 %1, %1, %1" : "+v"(a0), "+v"(r0));
+      a[0] = a0; R[0] = r0;
+      asm volatile("" : "+v"(a), "+v"(R));
     }
+    const double dpiv = readlane_f64(a[rg], 16 * g + c);   // a[c][c], updates of the steps < c applied
+    const double am = low ? a[rg] : 0.0;    // column c (row c of the symmetric block), masked
+    const double Rm = mine ? R[rg] : 0.0;
+    const double ri = rsqrt_seeded(dpiv);
     const double lcol = am * ri;   // L[lc][c]
     const double wrow = Rm * ri;   // W[c][lc]
     if (c < 15) {
-      // (the update of `a` is the one the next pivots wait for: it must enter the pipe first -- left alone,
-      //  the scheduler tends to issue the R update, whose operands are ready earlier, in front of it)
-      a = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, lcol, a, 0, 0, 1);   // blgp = 1: A operand negated
-      __builtin_amdgcn_sched_barrier(0);
-      R = __builtin_amdgcn_mfma_f64_16x16x4f64(lcol, wrow, R, 0, 0, 1);
+      // (the update of `a` is the one the next pivot waits for: it enters the pipe first)
+      asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %1, %0 neg:[1,0,0]" : "+v"(a) : "v"(lcol));
+      asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(R) : "v"(lcol), "v"(wrow));
     }
     baseL[g][c] = lcol;
     baseW[g][c] = wrow;
   }
   int bad = 0;
-  if (!(dmin >= 1e-30) || !(dpiv == dpiv)) {
+  {
+    const double last = LT[15 * PP + 15];
+    if (!(last == last)) {
 #pragma unroll
-    for (int c = 15; c >= 0; --c)
-      if (!(pivlog[c] >= 1e-30)) bad = 16 * k + c + 1;
+      for (int c = 15; c >= 0; --c) {
+        const double d = LT[c * PP + c];
+        if (!(d == d)) bad = 16 * k + c + 1;
+      }
+    }
   }
   return bad;
 }
