@@ -47,11 +47,11 @@ if PER_PANEL:
     sys.exit(0)
 # stamp slots: 0-2 common; 3-9 differ per role; 10-15 tail
 names_u = {0: "load X,y", 9: "K-build (own tiles)", 1: "K-build: barrier + image loads", 2: "prologue (park tiles)", 3: "wait cntT[k]", 4: "U1: col k+1, D_k+2 + park", 5: "wait flagW[k+1]",
-           6: "F: v, trsm, panel write, fold", 7: "U2: bulk update", 8: "column k+1 -> HBM", 15: "loop exit barrier", 11: "tail: scalars+copy+bar",
-           12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
+           6: "F: v, trsm, panel write, fold", 7: "U2: bulk update", 8: "column k+1 -> HBM", 15: "loop exit barrier", 11: "tail: M_k products+bar",
+           12: "-", 13: "backsub: wait alpha + folds", 14: "backsub: barrier", 10: "tail: rest"}
 names_p = {0: "load X,y", 8: "K-build (15 tile images)", 1: "K-build: barrier", 2: "prologue", 3: "wait cntS[j-2] (D_j, R_j)", 4: "own TRSM + diag update", 5: "potf2",
            9: "dl + publish", 15: "loop exit barrier",
-           11: "tail: scalars+copy+bar", 12: "backsub: matvec", 13: "backsub: tiles", 14: "backsub: barrier", 10: "tail: rest"}
+           11: "tail: scalars+bar", 12: "backsub: chain steps", 13: "backsub: wait for w_k", 14: "backsub: barrier", 10: "tail: rest"}
 med = np.median(s[:, 0], 0); medp = np.median(s[:, 1], 0); tot = med.sum(); totp = medp.sum()
 order = [0, 9, 8, 1, 2, 3, 4, 5, 6, 7, 15, 11, 12, 13, 14, 10] if False else [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 11, 12, 13, 14, 10]
 print(f"{'update wave 0':30s} {'cycles':>9s} {'%':>6s}   | {'panel wave':30s} {'cycles':>9s} {'%':>6s}")
