@@ -1,7 +1,7 @@
 """GPU parity tests of the fused fit at the edges of its shape space: single points, one task, many small
 tasks (more workgroups than CUs), N off the 16-grid, empty and one-point ragged tasks, large D.
-Held to 1e-9 on L / MLL and 1e-6 on alpha against the oracle evaluated with the kernels' own distance
-formulation (north_star asks 1e-4 / 1e-3)."""
+Held to 1e-9 on L / MLL and 1e-6 on alpha against the oracle evaluated with direct coordinate differences (the
+kernel forms the squared distances in gpytorch's expanded form on the matrix core; north_star asks 1e-4 / 1e-3)."""
 import pytest
 import torch
 
@@ -61,3 +61,47 @@ def test_fit_conditioning_stress(ls, noise, kind, device):
     torch.testing.assert_close(out["alpha"].cpu(), ref["alpha"], rtol=1e-4, atol=1e-4 * float(ref["alpha"].abs().max()))
     torch.testing.assert_close(out["mll"].cpu(), ref["mll"], rtol=1e-3, atol=0)
     torch.testing.assert_close(out["L"].cpu(), ref["L"], rtol=1e-6, atol=1e-9)
+
+
+def test_largest_supported_dimension_and_beyond(device):
+    # the staged point stack (D rounded up to 4, + 4 tail rows) has to fit the LDS next to the panels
+    from scamlgp_amd import _lib
+    N = 256
+    dmax = _lib.lib.scaml_fit_max_d(N)
+    assert dmax >= 32
+    g = torch.Generator().manual_seed(11)
+    for D, ok in ((dmax, True), (dmax + 1, False)):
+        X = torch.rand(2, N, D, dtype=torch.float64, generator=g)
+        y = torch.randn(2, N, dtype=torch.float64, generator=g)
+        theta = torch.cat([torch.full((2, D), 0.5 * D ** 0.5), torch.ones(2, 1), torch.full((2, 1), 1e-3)], 1).double()
+        if ok:
+            out = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), O.KIND_MATERN52)
+            assert not out["info"].cpu().any()
+            ref = O.gp_fit(X[1], y[1], theta[1], O.KIND_MATERN52, dist="direct")
+            torch.testing.assert_close(out["L"][1].cpu(), ref["L"], rtol=1e-9, atol=1e-11)
+            torch.testing.assert_close(out["mll"][1].cpu(), ref["mll"], rtol=1e-9, atol=1e-12)
+        else:
+            with pytest.raises(Exception):
+                ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), O.KIND_MATERN52)
+
+
+def test_expanded_distance_under_cancellation(device):
+    # short lengthscales make |x'|^2 large against the distances of close points: the expanded form
+    # |a|^2 + |b|^2 - 2 a.b loses digits there (as gpytorch's does); near-duplicates + exact duplicates included.
+    # Tolerances: north_star's 1e-4 on alpha / 1e-3 on the MLL.
+    T, N, D = 3, 96, 8
+    g = torch.Generator().manual_seed(5)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g)
+    X[:, 1] = X[:, 0] + 1e-6      # near-duplicate
+    X[:, 3] = X[:, 2]             # exact duplicate
+    y = torch.randn(T, N, dtype=torch.float64, generator=g)
+    for ls in (0.02, 0.2):
+        theta = torch.cat([torch.full((T, D), ls), torch.ones(T, 1), torch.full((T, 1), 1e-3)], 1).double()
+        for kind in (O.KIND_MATERN52, O.KIND_RBF):
+            out = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind)
+            assert not out["info"].cpu().any()
+            for t in range(T):
+                ref = O.gp_fit(X[t], y[t], theta[t], kind, dist="direct")
+                torch.testing.assert_close(out["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-7)
+                torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)
+                torch.testing.assert_close(out["L"][t].cpu(), ref["L"], rtol=1e-4, atol=1e-7)
