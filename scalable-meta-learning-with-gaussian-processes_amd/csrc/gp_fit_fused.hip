@@ -1092,4 +1092,5 @@ __global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p
 SCAML_INSTANTIATE(2, 1)
 SCAML_INSTANTIATE(4, 3)
 SCAML_INSTANTIATE(8, 3)
+SCAML_INSTANTIATE(8, 7)   // wide variant for N <= 128: one workgroup per CU, used when the tasks do not fill the CUs twice
 SCAML_INSTANTIATE(16, 7)

@@ -38,7 +38,9 @@ struct Module {
   std::mutex mu;
   bool loaded = false;
   hipModule_t mod = nullptr;
-  FitVariant fit[4] = {{2, 1, {nullptr, nullptr}}, {4, 3, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}}};
+  FitVariant fit[5] = {{2, 1, {nullptr, nullptr}}, {4, 3, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}},
+                       {8, 7, {nullptr, nullptr}}};   // [4]: wide variant for 64 < N <= 128
+  int num_cus = 0;
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t post_linv[2] = {nullptr, nullptr};
@@ -129,7 +131,18 @@ static int fit_common(scaml::FitParams p, int kind, void* stream) {
     return SCAML_E_LAUNCH;
   }
   const int N = p.N;
-  const FitVariant& v = m.fit[N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3))];
+  int vi = N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3));
+  if (vi == 2) {
+    // 64 < N <= 128: four waves per task let two workgroups share a CU; when the stack does not fill the CUs even
+    // once that buys nothing, and eight waves on the task's kernel matrix and trailing update are faster
+    if (m.num_cus == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.num_cus = cus;
+      if (m.num_cus <= 0) m.num_cus = 256;
+    }
+    if (p.T <= m.num_cus) vi = 4;
+  }
+  const FitVariant& v = m.fit[vi];
   const size_t lds = fit_lds_bytes(v.nb, v.wu, p.D);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
   size_t psize = sizeof(p);

@@ -183,3 +183,21 @@ def test_rejects_cpu_tensors_and_wrong_dtype(device):
     with pytest.raises(ValueError):
         ops.gp_fit_fused(torch.rand(2, 600, 2, dtype=torch.float64, device=device), torch.rand(2, 600, dtype=torch.float64, device=device),
                          theta.to(device), O.KIND_RBF)   # beyond the two-block limit of 512 points
+
+
+def test_narrow_and_wide_kernels_for_n_up_to_128_agree(device):
+    # 64 < N <= 128 has two kernels: four waves per task (two workgroups share a CU) for stacks that fill the CUs,
+    # eight waves per task otherwise (csrc/scaml_host.cpp).  Same stack through both; the first tasks vs the oracle.
+    T, N, D = 300, 100, 5
+    X, y, theta = _stack(T, N, D, seed=21)
+    Xd, yd, td = X.to(device), y.to(device), theta.to(device)
+    narrow = ops.gp_fit_fused(Xd, yd, td, O.KIND_MATERN52)                 # T > number of CUs
+    wide = ops.gp_fit_fused(Xd[:40].contiguous(), yd[:40].contiguous(), td[:40].contiguous(), O.KIND_MATERN52)
+    assert not narrow["info"].cpu().any() and not wide["info"].cpu().any()
+    torch.testing.assert_close(narrow["L"][:40], wide["L"], rtol=1e-12, atol=1e-14)
+    torch.testing.assert_close(narrow["alpha"][:40], wide["alpha"], rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(narrow["mll"][:40], wide["mll"], rtol=1e-12, atol=0)
+    for t in (0, 39):
+        ref = O.gp_fit(X[t], y[t], theta[t], O.KIND_MATERN52)
+        torch.testing.assert_close(wide["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-8)   # north_star: 1e-4
+        torch.testing.assert_close(narrow["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)     # north_star: 1e-3

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 bad = 0
-for (T, N, D, kind) in [(512, 256, 8, 1), (512, 128, 4, 0), (512, 200, 3, 1), (1024, 64, 2, 0), (1024, 32, 2, 1), (512, 100, 5, 0)]:
+for (T, N, D, kind) in [(512, 256, 8, 1), (512, 128, 4, 0), (512, 200, 3, 1), (1024, 64, 2, 0), (1024, 32, 2, 1), (512, 100, 5, 0), (200, 128, 4, 1), (256, 100, 5, 0)]:   # the last two: the wide 8-wave variant for N <= 128 (T <= CUs)
     X = torch.rand(T, N, D, dtype=torch.float64, device=dev)
     y = torch.randn(T, N, dtype=torch.float64, device=dev)
     theta = torch.cat([0.3 + torch.rand(T, D, dtype=torch.float64, device=dev), torch.ones(T, 1, dtype=torch.float64, device=dev),
