@@ -84,43 +84,114 @@ __global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
   if (16 * strip >= R) return;
   const int qc = 16 * strip + lc;
   // forward substitution
+  LRowSeg q[4];   // the next four L tiles (row segments) of the substitution, in flight
+  auto fetch4 = [&](int kbr, int jf) {   // tiles jf .. jf + 3 of block row kbr (zeros past the diagonal / the matrix)
+    const int arow = 16 * kbr + lc;
+    const bool arow_ok = kbr < NB && arow < n;
+    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
+    const bool rows_in = 16 * kbr + 16 <= n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jf + u;
+      if (kbr < NB && j < kbr) {
+        q[u] = load_lrow_seg(Lrow, 16 * j + 4 * lq, rows_in && (N & 1) == 0 && 16 * j + 16 <= n, arow_ok, n);
+      } else {
+        q[u].a[0] = q[u].a[1] = q[u].a[2] = q[u].a[3] = 0.0;
+      }
+    }
+  };
+  // (W_kb and the right-hand side rows of a block are fetched one block ahead as well)
+  double wn[4], bn[4];
+  auto fetch_wb = [&](int kbn) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      wn[m] = kbn < NB ? Wg[(size_t)kbn * 256 + lc * 16 + lq + 4 * m] : 0.0;
+      const int row = 16 * kbn + lq + 4 * m;
+      bn[m] = (kbn < NB && row < n && qc < R) ? Bg[(size_t)row * R + qc] : 0.0;
+    }
+  };
+  fetch_wb(0);
   for (int kb = 0; kb < NB; ++kb) {
     d4_t acc;
+    double wc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = 16 * kb + lq + 4 * g;
-      acc[g] = (row < n && qc < R) ? Bg[(size_t)row * R + qc] : 0.0;
+    for (int g = 0; g < 4; ++g) { acc[g] = bn[g]; wc[g] = wn[g]; }
+    fetch_wb(kb + 1);
+    // acc -= sum_{j < kb} L[kb, j] V_j.  A wave works alone on its strip here (R <= 16 right-hand sides: ONE wave
+    // per task), so the L row segments are fetched four tiles ahead -- across the end of a block row into the
+    // first tiles of the next one -- instead of one (subst_accumulate): every tile product used to expose most
+    // of a global-load latency.
+    for (int j0 = 0; j0 < kb; j0 += 4) {
+      LRowSeg cur[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = q[u];
+      if (j0 + 4 < kb) fetch4(kb, j0 + 4); else fetch4(kb + 1, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < kb) {
+          const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u].a[m], vb[4 * m * 16], acc, 0, 0, 1);
+        }
+      }
     }
-    const int arow = 16 * kb + lc;
-    const bool arow_ok = arow < n;
-    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    acc = subst_accumulate(acc, Lrow, arow_ok, 16 * kb + 16 <= n, n, (N & 1) == 0, Vs, 0, kb, lc, lq);
+    if (kb == 0) fetch4(1, 0);
     d4_t v = {0.0, 0.0, 0.0, 0.0};
-    const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[m], acc[m], v, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
   }
   // backward substitution (in place in the strip: block kb is overwritten once all j > kb are final)
+  double un[4];   // A[i = lc][k = lq] = W[4 m + lq][lc] of the next block, one block ahead
+  auto fetch_wt = [&](int kbn) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) un[m] = kbn >= 0 ? Wg[(size_t)kbn * 256 + lq * 16 + lc + 4 * m * 16] : 0.0;
+  };
+  fetch_wt(NB - 1);
   for (int kb = NB - 1; kb >= 0; --kb) {
     d4_t acc;
+    double uc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = Vs[(16 * kb + strip_row(lq, g)) * 16 + lc];
-    for (int j = kb + 1; j < NB; ++j) {
-      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+    for (int g = 0; g < 4; ++g) { acc[g] = Vs[(16 * kb + strip_row(lq, g)) * 16 + lc]; uc[g] = un[g]; }
+    fetch_wt(kb - 1);
+    // A[i = lc][k] = L[16 j + k][16 kb + lc] (the transposed tile), k = 4 lq + m as in the strip's row order.
+    // The tiles of block column kb are known in advance: four of them (16 values per lane) are in flight while
+    // the MFMAs of the previous four run -- with the load issued right in front of its MFMA every one of the
+    // NB (NB - 1) / 2 tile products exposed a full global-load latency.
+    auto load_tile = [&](int j, double (&a)[4]) {
+      const int c = 16 * kb + lc;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        // A[i = lc][k] = L[16 j + k][16 kb + lc] (the transposed tile), k = 4 lq + m as in the strip's row order
-        const int r = 16 * j + 4 * lq + m, c = 16 * kb + lc;
-        const double a = (r < n && c < n) ? Lg[(size_t)r * N + c] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[4 * m * 16], acc, 0, 0, 1);
+        const int r = 16 * j + 4 * lq + m;
+        a[m] = (j < NB && r < n && c < n) ? Lg[(size_t)r * N + c] : 0.0;
+      }
+    };
+    double nx[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_tile(kb + 1 + u, nx[u]);
+    for (int j0 = kb + 1; j0 < NB; j0 += 4) {
+      double cur[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cur[u][m] = nx[u][m];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load_tile(j0 + 4 + u, nx[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < NB) {
+          const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u][m], vb[4 * m * 16], acc, 0, 0, 1);
+        }
       }
     }
     d4_t v = {0.0, 0.0, 0.0, 0.0};
-    const double* wcol = Wg + (size_t)kb * 256 + lq * 16 + lc;   // A[i = lc][k = lq] = W[4 m + lq][lc]
 #pragma unroll
-    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wcol[4 * m * 16], acc[m], v, 0, 0, 0);
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(uc[m], acc[m], v, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = 16 * kb + lq + 4 * g;
