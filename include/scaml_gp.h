@@ -150,6 +150,10 @@ int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* th
  */
 int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
                                 int T, int N, int R, double* Xout, void* stream);
+/* The backward half alone: Xout = L^-T B (linear_operator's TriangularLinearOperator.solve with upper = True behind
+ * the same caches).  With V = L^-1 K_* at hand, K^-1 K_* a = L^-T (V a) needs only this. */
+int scaml_solve_lt_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                               int T, int N, int R, double* Xout, void* stream);
 
 /*
  * (6) Weighted sum over the task axis: out[e] = sum_t c_t in[t][e], c_t = w_t (power 1) or w_t^2

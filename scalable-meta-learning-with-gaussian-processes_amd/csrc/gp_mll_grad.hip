@@ -110,8 +110,18 @@ __global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
       bn[m] = (kbn < NB && row < n && qc < R) ? Bg[(size_t)row * R + qc] : 0.0;
     }
   };
+  if (p.mode == 1) {
+    // backward substitution only: the right-hand side goes into the strip as it is
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * kb + lq + 4 * g;
+        Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = (row < n && qc < R) ? Bg[(size_t)row * R + qc] : 0.0;
+      }
+    }
+  }
   fetch_wb(0);
-  for (int kb = 0; kb < NB; ++kb) {
+  for (int kb = 0; kb < (p.mode == 1 ? 0 : NB); ++kb) {
     d4_t acc;
     double wc[4];
 #pragma unroll

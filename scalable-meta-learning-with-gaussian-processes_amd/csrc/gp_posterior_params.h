@@ -38,8 +38,9 @@ struct ChoSolveParams {
   const double* Linv_diag;  // (T, ceil(N/16), 16, 16)
   const double* B;          // (T, N, R) right-hand sides
   const int32_t* n_points;  // (T) or NULL
-  double* Xout;             // (T, N, R): (L L^T)^-1 B
+  double* Xout;             // (T, N, R): (L L^T)^-1 B, or L^-T B (mode 1)
   int T, N, R;
+  int mode;                 // 0: forward + backward substitution, 1: backward only (L^T x = b)
 };
 
 struct KernelMatrixParams {

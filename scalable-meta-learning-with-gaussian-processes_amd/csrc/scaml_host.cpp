@@ -282,8 +282,8 @@ int scaml_kernel_matrix_f64(const double* X1, const double* X2, const double* th
 }
 
 // ---- batched Cholesky solve ----------------------------------------------------------------------
-int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
-                                int T, int N, int R, double* Xout, void* stream) {
+static int cho_solve_common(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                           int T, int N, int R, double* Xout, int mode, void* stream) {
   if (T < 0 || N < 1 || R < 0) return SCAML_E_BADARG;
   if (!L || !Linv_diag || !B || !Xout) return SCAML_E_BADARG;
   if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
@@ -294,13 +294,23 @@ int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const 
   const int nb = (N + 15) / 16, np = nb * 16, strips = (R + 15) / 16;
   int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
   if (waves > strips) waves = strips;
-  scaml::ChoSolveParams p{L, Linv_diag, B, n_points, Xout, T, N, R};
+  scaml::ChoSolveParams p{L, Linv_diag, B, n_points, Xout, T, N, R, mode};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   e = hipModuleLaunchKernel(m.chosolve, (unsigned)((strips + waves - 1) / waves), (unsigned)T, 1, (unsigned)waves * 64, 1, 1,
                             (unsigned)((size_t)waves * np * 16 * 8), (hipStream_t)stream, nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_cho_solve)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
+}
+
+int scaml_cho_solve_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                                int T, int N, int R, double* Xout, void* stream) {
+  return cho_solve_common(L, Linv_diag, B, n_points, T, N, R, Xout, 0, stream);
+}
+
+int scaml_solve_lt_batched_f64(const double* L, const double* Linv_diag, const double* B, const int32_t* n_points,
+                               int T, int N, int R, double* Xout, void* stream) {
+  return cho_solve_common(L, Linv_diag, B, n_points, T, N, R, Xout, 1, stream);
 }
 
 // the weighted target prior in one call: mean with w, covariance with w^2 (two launches of the sum kernel)

@@ -86,6 +86,8 @@ def _load() -> ctypes.CDLL:
     ]
     lib.scaml_cho_solve_batched_f64.restype = c_int
     lib.scaml_cho_solve_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, c_void_p]
+    lib.scaml_solve_lt_batched_f64.restype = c_int
+    lib.scaml_solve_lt_batched_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, _dp, c_void_p]
     lib.scaml_weighted_task_sum_f64.restype = c_int
     lib.scaml_weighted_task_sum_f64.argtypes = [_dp, _dp, _dp, c_int, ctypes.c_longlong, c_int, _dp, c_void_p]
     lib.scaml_weighted_prior_reduce_f64.restype = c_int
@@ -114,6 +116,7 @@ EXPORTED_SYMBOLS = (
     "scaml_linv_batched_f64",
     "scaml_posterior_linv_f64",
     "scaml_cho_solve_batched_f64",
+    "scaml_solve_lt_batched_f64",
     "scaml_weighted_task_sum_f64",
     "scaml_weighted_prior_reduce_f64",
     "scaml_mll_backward_workspace_doubles",

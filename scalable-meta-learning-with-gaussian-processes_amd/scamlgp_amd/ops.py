@@ -125,7 +125,7 @@ def _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry) -> Di
 
     The posterior of block 1 at the points of block 2 is exactly the conditional the Schur complement
     needs: alpha_2 = S^-1 (y_2 - K21 K11^-1 y_1) falls out of the POTRF's solve, and
-    alpha_1 = alpha_1' - K11^-1 K12 alpha_2 (mean-only cross product + scaml_cho_solve_batched_f64).
+    alpha_1 = alpha_1' - K11^-1 K12 alpha_2 = alpha_1' - L11^-T (V alpha_2) (scaml_solve_lt_batched_f64).
     quad and logdet add over the blocks.  The jitter ladder is driven from the host here (one
     status read per attempt; every attempt is single-shot in the kernels) so that, like
     psd_safe_cholesky, one jitter value applies to the whole matrix of a failing task only.
@@ -157,8 +157,9 @@ def _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry) -> Di
         if not retry or step == len(_JITTER_LADDER) or not bool(failed.any()):
             break
         jit = torch.where(failed, torch.full_like(jit, _JITTER_LADDER[step]), jit)
-    k12a2 = source_posteriors(X1, X2, theta, kind, None, None, f2["alpha"], n_points=n2, mean_only=True)["mean"]
-    u = cho_solve(f1["L"], f1["Linv_diag"], k12a2.unsqueeze(-1), n_points=n1).squeeze(-1)
+    # K11^-1 K12 alpha_2 = L11^-T (V alpha_2) with the V = L11^-1 K12 the Schur complement was formed from: a
+    # mat-vec and the backward half of a Cholesky solve (alpha_2 is zero past n2, so V's padded columns drop out)
+    u = cho_solve(f1["L"], f1["Linv_diag"], torch.bmm(p12["V"], f2["alpha"].unsqueeze(-1)), n_points=n1, backward_only=True).squeeze(-1)
     alpha = torch.cat([f1["alpha"] - u, f2["alpha"]], 1)
     quad = f1["quad"] + f2["quad"]
     logdet = f1["logdet"] + f2["logdet"]
@@ -191,8 +192,10 @@ def linv_batched(L: torch.Tensor, Linv_diag: torch.Tensor, n_points: Optional[to
     return out
 
 
-def cho_solve(L: torch.Tensor, Linv_diag: torch.Tensor, B: torch.Tensor, n_points: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """(L L^T)^-1 B for B (T, N, R) with the factors of a fused fit.  scaml_cho_solve_batched_f64."""
+def cho_solve(L: torch.Tensor, Linv_diag: torch.Tensor, B: torch.Tensor, n_points: Optional[torch.Tensor] = None,
+              backward_only: bool = False) -> torch.Tensor:
+    """(L L^T)^-1 B for B (T, N, R) with the factors of a fused fit (scaml_cho_solve_batched_f64), or, with
+    backward_only, L^-T B (scaml_solve_lt_batched_f64)."""
     T, N, _ = L.shape
     R = B.shape[-1]
     L = _check(L, "L", (T, N, N))
@@ -202,9 +205,9 @@ def cho_solve(L: torch.Tensor, Linv_diag: torch.Tensor, B: torch.Tensor, n_point
         n_points = _check(n_points, "n_points", (T,), torch.int32)
     out = torch.empty_like(B)
     with torch.cuda.device(L.device):
-        rc = _lib.lib.scaml_cho_solve_batched_f64(_ptr(L), _ptr(Linv_diag), _ptr(B), _ptr(n_points), T, N, R, _ptr(out),
-                                                  _stream_handle())
-    _lib.check_rc(rc, "scaml_cho_solve_batched_f64")
+        fn = _lib.lib.scaml_solve_lt_batched_f64 if backward_only else _lib.lib.scaml_cho_solve_batched_f64
+        rc = fn(_ptr(L), _ptr(Linv_diag), _ptr(B), _ptr(n_points), T, N, R, _ptr(out), _stream_handle())
+    _lib.check_rc(rc, "scaml_solve_lt_batched_f64" if backward_only else "scaml_cho_solve_batched_f64")
     return out
 
 

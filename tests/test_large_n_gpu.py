@@ -96,6 +96,9 @@ def test_cho_solve_matches_torch(N, R, device):
         Ld = L.to(device)
     got = ops.cho_solve(Ld, W, rhs.to(device)).cpu()
     torch.testing.assert_close(got, torch.cholesky_solve(rhs, L), rtol=1e-8, atol=1e-10)
+    # the backward half alone (scaml_solve_lt_batched_f64): L^T x = b
+    got_t = ops.cho_solve(Ld, W, rhs.to(device), backward_only=True).cpu()
+    torch.testing.assert_close(got_t, torch.linalg.solve_triangular(L.transpose(-1, -2), rhs, upper=True), rtol=1e-8, atol=1e-10)
     n = torch.tensor([N, max(N - 7, 1), 1], dtype=torch.int32)
     if N <= 256:
         f = ops.potrf_batched(A.to(device), n_points=n.to(device), want_linv=True)
@@ -105,6 +108,12 @@ def test_cho_solve_matches_torch(N, R, device):
             ref = torch.cholesky_solve(rhs[t, :k], torch.linalg.cholesky(A[t, :k, :k]))
             torch.testing.assert_close(got[t, :k], ref, rtol=1e-8, atol=1e-10)
             assert float(got[t, k:].abs().sum()) == 0.0
+        got_t = ops.cho_solve(f["L"], f["Linv_diag"], rhs.to(device), n_points=n.to(device), backward_only=True).cpu()
+        for t in range(T):
+            k = int(n[t])
+            Lk = torch.linalg.cholesky(A[t, :k, :k])
+            torch.testing.assert_close(got_t[t, :k], torch.linalg.solve_triangular(Lk.T, rhs[t, :k], upper=True), rtol=1e-8, atol=1e-10)
+            assert float(got_t[t, k:].abs().sum()) == 0.0
 
 
 def test_posterior_per_task_queries_and_mean_only(device):
