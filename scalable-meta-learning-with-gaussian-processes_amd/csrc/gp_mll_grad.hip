@@ -232,14 +232,18 @@ template <int KIND>
 __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   __shared__ double exptab[64];
   __shared__ double invl_s[64];   // 1 / lengthscale (D <= 64: larger D take the division)
-  extern __shared__ double xstage[];   // [waves][32][D] scaled points of the two blocks of a tile
+  extern __shared__ double xstage[];   // [waves][64][D | 1] scaled points of the four blocks of a super-tile
   const int N = p.N, D = p.D, NB = (N + 15) / 16;
   const int NT = NB * (NB + 1) / 2;
   // XCD-aware block -> (task, tile group) map.  Workgroups go to the 8 XCDs round-robin by linear id, and
   // each XCD has its own 4 MB L2: all tile groups of one task are therefore given ids that are congruent
   // mod 8, so that the task's L^-1 (re-read by every tile of its column / row) stays in ONE L2 instead of
   // being fetched from HBM by all eight.  1-D grid of ceil(T / 8) * 8 * groups blocks.
-  const int groups = (NT + 3) / 4;
+  // A wave owns a SUPER-tile of 2 x 2 tiles (block rows 2 SA, 2 SA + 1; block columns 2 SC, 2 SC + 1): its K^-1
+  // loop loads four 16-row segments per trip for up to 16 MFMAs.  With one tile per wave the loop moved 4 KB per
+  // 4 MFMAs and CU -- the vector L1's 64 B/clk exactly at the MFMA rate -- and ran load-bound.
+  const int NBS = (NB + 1) / 2, NS = NBS * (NBS + 1) / 2;
+  const int groups = (NS + 3) / 4;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int task = (slot / groups) * 8 + xcd;
   const int group = slot % groups;
@@ -249,12 +253,14 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   exp2_table_init(exptab, tid);
   if (tid < D && tid < 64) invl_s[tid] = 1.0 / p.theta[(size_t)task * (D + 2) + tid];
   __syncthreads();
-  const int tile = group * (blockDim.x >> 6) + wave;
-  if (tile >= NT) return;
-  // tile -> (ta >= tc), column-major over the lower triangle
-  int tc = 0, off = 0;
-  while (tc < NB - 1 && off + (NB - tc) <= tile) { off += NB - tc; ++tc; }
-  const int ta = tc + (tile - off);
+  const int stile = group * (blockDim.x >> 6) + wave;
+  if (stile >= NS) return;
+  // super-tile -> (SA >= SC), column-major over the lower triangle of super-blocks
+  int SC = 0, soff = 0;
+  while (SC < NBS - 1 && soff + (NBS - SC) <= stile) { soff += NBS - SC; ++SC; }
+  const int SA = SC + (stile - soff);
+  const bool diag = SA == SC;
+  const int ta0 = 2 * SA, ta1 = 2 * SA + 1, tc0 = 2 * SC, tc1 = 2 * SC + 1;   // (ta1 / tc1 may be >= NB: N % 32 in (0, 16])
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
   const double* th = p.theta + (size_t)task * (D + 2);
@@ -262,83 +268,140 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   const double* Xg = p.X + (size_t)task * N * D;
   const double* al = p.alpha + (size_t)task * N;
   const double* Li = p.Linv + (size_t)task * N * N;
-  // K^-1 tile: sum_r Linv[r][a] Linv[r][c], r >= 16 ta (Linv is lower triangular, a >= c)
-  const int pa = 16 * ta + lc, pc = 16 * tc + lc;
-  d4_t kin = {0.0, 0.0, 0.0, 0.0};
-  // (16 rows per trip: the eight loads of a trip are issued together, then four MFMAs -- one exposed
-  //  memory latency per 16 rows instead of per 4)
-  const bool cols_in = 16 * ta + 16 <= N;   // then pc < pa < N for every lane
-  int r0 = 16 * ta;
-  if (cols_in) {
-    for (; r0 + 16 <= N; r0 += 16) {
-      const double* row = Li + (size_t)(r0 + lq) * N;
-      double av[4], bv[4];
+  // K^-1 tiles: sum_r Linv[r][a] Linv[r][c] over r >= 16 ta0 (Linv is lower triangular: the rows of block ta0 are
+  // zero in the columns of block ta1, one trip of zeros for that tile).  kin[i][j] <-> tile (ta_i, tc_j).
+  d4_t k00 = {0.0, 0.0, 0.0, 0.0}, k01 = k00, k10 = k00, k11 = k00;
+  // The 64 points of the four blocks (scaled by 1 / l) go into the wave's LDS slab once per super-tile -- before the
+  // K^-1 loop, so that their global-load latency runs under it; odd pitch: the epilogue reads one dimension of 16
+  // different points at a time.  Element e = lane + 64 i <-> (point e / D, dimension e % D), stepped without division.
+  const int DP = (D + 1) | 1;   // column D carries alpha
+  double* xs = xstage + (size_t)wave * 64 * DP;   // points 0..15 block ta0, 16..31 ta1, 32..47 tc0, 48..63 tc1
+  {
+    int r = lane / D, d = lane - r * D;
+    const int dr = 64 / D, dd = 64 - dr * D;
+    for (int e = lane; e < 64 * D; e += 64) {
+      const int blk = r >> 4;
+      const int tb = blk == 0 ? ta0 : (blk == 1 ? ta1 : (blk == 2 ? tc0 : tc1));
+      const int row = 16 * tb + (r & 15);
+      const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
+      xs[r * DP + d] = (tb < NB && row < n) ? Xg[(size_t)row * D + d] * il : 0.0;
+      r += dr; d += dd;
+      if (d >= D) { d -= D; ++r; }
+    }
+    {
+      const int blk = lane >> 4;
+      const int tb = blk == 0 ? ta0 : (blk == 1 ? ta1 : (blk == 2 ? tc0 : tc1));
+      const int row = 16 * tb + (lane & 15);
+      xs[lane * DP + D] = (tb < NB && row < n) ? al[row] : 0.0;
+    }
+  }
+  const int pa0 = 16 * ta0 + lc, pa1 = 16 * ta1 + lc, pc0 = 16 * tc0 + lc, pc1 = 16 * tc1 + lc;
+  int r0 = 16 * ta0;
+  if (ta1 < NB && 16 * ta1 + 16 <= N) {   // every column of the four blocks is inside the matrix
+    // (double-buffered: the 8 / 16 loads of the next trip are in flight while the 12 / 16 MFMAs of this one run --
+    //  a trip is otherwise one exposed L2 latency, ~5 x its MFMA time)
+    double na0[4], na1[4], nb0[4], nb1[4];
+    auto fetch = [&](int rr) {
+      const double* row = Li + (size_t)(rr + lq) * N;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        av[u] = row[(size_t)4 * u * N + pa];
-        bv[u] = row[(size_t)4 * u * N + pc];
+        na0[u] = row[(size_t)4 * u * N + pa0];
+        na1[u] = row[(size_t)4 * u * N + pa1];
       }
+      if (!diag) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kin = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], kin, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          nb0[u] = row[(size_t)4 * u * N + pc0];
+          nb1[u] = row[(size_t)4 * u * N + pc1];
+        }
+      }
+    };
+    if (r0 + 16 <= N) fetch(r0);
+    for (; r0 + 16 <= N; r0 += 16) {
+      double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0[u] = na0[u]; a1[u] = na1[u];
+        b0[u] = diag ? na0[u] : nb0[u];
+        b1[u] = diag ? na1[u] : nb1[u];
+      }
+      if (r0 + 32 <= N) fetch(r0 + 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], k00, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], k10, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], k11, 0, 0, 0);
+      if (!diag) {   // (the tile above the diagonal of a diagonal super-tile is not needed)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], k01, 0, 0, 0);
+      }
     }
   }
   for (; r0 < N; r0 += 4) {
     const int r = r0 + lq;
-    const double a = (r < N && pa < N) ? Li[(size_t)r * N + pa] : 0.0;
-    const double b = (r < N && pc < N) ? Li[(size_t)r * N + pc] : 0.0;
-    kin = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, kin, 0, 0, 0);
+    const bool rin = r < N;
+    const double a0 = (rin && pa0 < N) ? Li[(size_t)r * N + pa0] : 0.0;
+    const double a1 = (rin && ta1 < NB && pa1 < N) ? Li[(size_t)r * N + pa1] : 0.0;
+    const double b0 = (rin && pc0 < N) ? Li[(size_t)r * N + pc0] : 0.0;
+    const double b1 = (rin && tc1 < NB && pc1 < N) ? Li[(size_t)r * N + pc1] : 0.0;
+    k00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, k00, 0, 0, 0);
+    k10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, k10, 0, 0, 0);
+    k11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, k11, 0, 0, 0);
+    k01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, k01, 0, 0, 0);
   }
-  // epilogue: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc.  The 32 points of the two
+  // epilogue per tile: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc.  The 32 points of the two
   // blocks are staged (scaled by 1 / l) in the wave's LDS slab, so that both passes over the dimensions are
   // LDS reads, and the D + 2 sums are reduced over the wave at the very end, back to back.
-  const double wgt = ta == tc ? 1.0 : 2.0;
-  double* outp = p.partials + ((size_t)task * NT + tile) * (D + 2);
-  double* xs = xstage + (size_t)wave * 32 * D;   // [32][D]: rows 0..15 block ta, 16..31 block tc
-  for (int e = lane; e < 32 * D; e += 64) {
-    const int r = e / D, d = e - r * D;
-    const int row = (r < 16 ? 16 * ta : 16 * tc - 16) + r;
-    const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
-    xs[e] = row < n ? Xg[(size_t)row * D + d] * il : 0.0;
-  }
-  // (same wave writes and reads: LDS is in order, no barrier needed)
-  const double ac = pc < n ? al[pc] : 0.0;
-  double G[4], hk[4];
-  double g_os = 0.0, g_noise = 0.0;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int a = 16 * ta + lq + 4 * g;
-    const bool ok = a < n && pc < n;
-    double d2 = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double df = xs[(lq + 4 * g) * D + d] - xs[(16 + lc) * D + d];
-      d2 = __builtin_fma(df, df, d2);
-    }
-    double k, h;
-    kernel_and_dfactor<KIND>(d2, exptab, k, h);
-    const double Gv = ok ? wgt * (al[a < N ? a : 0] * ac - kin[g]) : 0.0;
-    G[g] = Gv * os;   // (os folded in: every lengthscale term carries it)
-    hk[g] = h;
-    g_os = __builtin_fma(Gv, k, g_os);
-    if (a == pc) g_noise += Gv;
-  }
-  // lengthscales: d mll / d l_d ~ sum G os h delta_d^2 / l_d^3 with delta / l already in LDS: sum G os h (delta/l)^2 / l
-  for (int d = 0; d < D; ++d) {
-    double s = 0.0;
+  auto epilogue = [&](const int ta, const int tc, const int xa, const int xc, const d4_t kin) {   // xa / xc: first staged point of the blocks
+    const int pc = 16 * tc + lc;
+    const int tile = tc * NB - tc * (tc - 1) / 2 + (ta - tc);   // column-major index over the lower triangle of tiles
+    const double wgt = ta == tc ? 1.0 : 2.0;
+    double* outp = p.partials + ((size_t)task * NT + tile) * (D + 2);
+    // (the points were staged by this wave itself: LDS is in order, no barrier needed)
+    const double ac = xs[(xc + lc) * DP + D];   // alpha, staged with the points (0 past n)
+    double G[4], hk[4];
+    double g_os = 0.0, g_noise = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const double df = xs[(lq + 4 * g) * D + d] - xs[(16 + lc) * D + d];
-      s = __builtin_fma(G[g] * hk[g], df * df, s);
+      const int a = 16 * ta + lq + 4 * g;
+      const bool ok = a < n && pc < n;
+      double d2 = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
+        d2 = __builtin_fma(df, df, d2);
+      }
+      double k, h;
+      kernel_and_dfactor<KIND>(d2, exptab, k, h);
+      const double Gv = ok ? wgt * (xs[(xa + lq + 4 * g) * DP + D] * ac - kin[g]) : 0.0;
+      G[g] = Gv * os;   // (os folded in: every lengthscale term carries it)
+      hk[g] = h;
+      g_os = __builtin_fma(Gv, k, g_os);
+      if (a == pc) g_noise += Gv;
     }
-    const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
-    s = wave_sum_to_lane15(s * il);
-    if (lane == 63) outp[d] = s;
-  }
-  g_os = wave_sum_to_lane15(g_os);
-  g_noise = wave_sum_to_lane15(g_noise);
-  if (lane == 63) {
-    outp[D] = g_os;        // = sum G k  (d K / d os = k)
-    outp[D + 1] = g_noise; // = tr G
-  }
+    // lengthscales: d mll / d l_d ~ sum G os h delta_d^2 / l_d^3 with delta / l already in LDS: sum G os h (delta/l)^2 / l
+    for (int d = 0; d < D; ++d) {
+      double s = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
+        s = __builtin_fma(G[g] * hk[g], df * df, s);
+      }
+      const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
+      s = wave_sum_to_lane15(s * il);
+      if (lane == 63) outp[d] = s;
+    }
+    g_os = wave_sum_to_lane15(g_os);
+    g_noise = wave_sum_to_lane15(g_noise);
+    if (lane == 63) {
+      outp[D] = g_os;        // = sum G k  (d K / d os = k)
+      outp[D + 1] = g_noise; // = tr G
+    }
+  };
+  epilogue(ta0, tc0, 0, 32, k00);
+  if (ta1 < NB) epilogue(ta1, tc0, 16, 32, k10);
+  if (ta1 < NB && tc1 < NB) epilogue(ta1, tc1, 16, 48, k11);
+  if (!diag && tc1 < NB) epilogue(ta0, tc1, 0, 48, k01);
 }
 
 }  // namespace scaml

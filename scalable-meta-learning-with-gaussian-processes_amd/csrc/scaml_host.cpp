@@ -85,6 +85,8 @@ struct Module {
       char name[128];
       snprintf(name, sizeof(name), "_ZN5scaml18gp_mll_grad_kernelILi%dEEEvNS_13MllGradParamsE", kind);
       if ((e = hipModuleGetFunction(&mllgrad[kind], mod, name)) != hipSuccess) return e;
+      // (the kernel also has 1 KB of static LDS)
+      if ((e = hipFuncSetAttribute((const void*)mllgrad[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)) != hipSuccess) return e;
       snprintf(name, sizeof(name), "_Z23gp_kernel_matrix_kernelILi%dEEvN5scaml18KernelMatrixParamsE", kind);
       if ((e = hipModuleGetFunction(&kmat[kind], mod, name)) != hipSuccess) return e;
     }
@@ -396,6 +398,7 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
   if (!X || !theta || !L || !Linv_diag || !alpha || !workspace) return SCAML_E_BADARG;
   if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
   if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if ((size_t)4 * 64 * ((D + 1) | 1) * sizeof(double) > 160 * 1024 - 2048) return SCAML_E_TOOLARGE;   // staged points of four waves (D <= 76)
   if (T == 0) return SCAML_OK;
   Module& m = module();
   hipError_t e = m.load();
@@ -412,8 +415,9 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     size_t psize = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
     // 1-D grid, XCD-aware (task, tile group) map inside the kernel
-    const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * (unsigned)((nt + 3) / 4);
-    e = hipModuleLaunchKernel(m.mllgrad[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(4 * 32 * D * sizeof(double)), (hipStream_t)stream,
+    const int nbs = (nb + 1) / 2, ns = nbs * (nbs + 1) / 2;   // 2 x 2 super-tiles, one per wave
+    const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * (unsigned)((ns + 3) / 4);
+    e = hipModuleLaunchKernel(m.mllgrad[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(4 * 64 * ((D + 1) | 1) * sizeof(double)), (hipStream_t)stream,
                               nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad)", e); return SCAML_E_LAUNCH; }
   }

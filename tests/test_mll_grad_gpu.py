@@ -31,6 +31,8 @@ def _autograd_grad(X, y, theta, kind):
     (2, 256, 8, O.KIND_MATERN52),
     (2, 400, 6, O.KIND_MATERN52),   # two-block fit (N > 256) feeding the same gradient kernels
     (2, 512, 6, O.KIND_RBF),
+    (2, 72, 40, O.KIND_MATERN52),   # large D: the staged points of a wave's four blocks need > 64 KB of LDS per workgroup
+    (3, 16, 1, O.KIND_RBF),         # one block: a super-tile with three absent tiles
 ])
 def test_mll_gradient_matches_autograd(T, N, D, kind, device):
     d = synthetic.smooth_field_task_stack(T, N, D, seed=20 + N)
