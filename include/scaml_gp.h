@@ -182,7 +182,8 @@ int scaml_weighted_prior_reduce_f64(const double* mu, const double* cov, const d
  * hold scaml_mll_backward_workspace_doubles(T, N, D) doubles (L^-1 per task, then per-tile partial
  * sums).  Result: partial sums (T, tiles, D+2), tiles = nb (nb+1)/2 with nb = ceil(N/16), written
  * to `partials_out` if given, else to the tail of the workspace; the caller adds them over the tile
- * axis and divides by 2 n_t (deterministic: no atomics).
+ * axis and divides by 2 n_t (deterministic: no atomics).  Only the sum over the tile axis is defined: the
+ * kernel works on 2 x 2 groups of tiles and leaves a group's total in the slot of its first tile.  D <= 76.
  */
 long long scaml_mll_backward_workspace_doubles(int T, int N, int D);
 int scaml_mll_backward_f64(const double* X, const double* theta, const double* L, const double* Linv_diag,

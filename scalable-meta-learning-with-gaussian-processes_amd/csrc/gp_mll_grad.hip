@@ -353,55 +353,78 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   // epilogue per tile: this lane owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc.  The 32 points of the two
   // blocks are staged (scaled by 1 / l) in the wave's LDS slab, so that both passes over the dimensions are
   // LDS reads, and the D + 2 sums are reduced over the wave at the very end, back to back.
-  auto epilogue = [&](const int ta, const int tc, const int xa, const int xc, const d4_t kin) {   // xa / xc: first staged point of the blocks
+  // Epilogue over the (up to) four tiles of the super-tile.  Pass A per tile: G = wgt (alpha alpha^T - K^-1), the
+  // kernel value k and the radial factor h for the lane's four elements; the D lengthscale sums, the outputscale
+  // and the noise sum are accumulated over ALL tiles of the super-tile and reduced over the wave once (the caller
+  // adds the per-tile partials up anyway: the super-tile's totals go into the slot of its first tile, zeros into
+  // the others).  Lane (lc, lq) owns rows a = 16 ta + lq + 4g, column c = 16 tc + lc of a tile.
+  const int tiles_ta[4] = {ta0, ta1, ta1, ta0}, tiles_tc[4] = {tc0, tc0, tc1, tc1};
+  const int tiles_xa[4] = {0, 16, 16, 0}, tiles_xc[4] = {32, 32, 48, 48};
+  const bool tiles_on[4] = {true, ta1 < NB, ta1 < NB && tc1 < NB, !diag && tc1 < NB};
+  double GH[4][4];
+  double g_os = 0.0, g_noise = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const d4_t kin = t == 0 ? k00 : (t == 1 ? k10 : (t == 2 ? k11 : k01));
+    const int ta = tiles_ta[t], tc = tiles_tc[t], xa = tiles_xa[t], xc = tiles_xc[t];
     const int pc = 16 * tc + lc;
-    const int tile = tc * NB - tc * (tc - 1) / 2 + (ta - tc);   // column-major index over the lower triangle of tiles
     const double wgt = ta == tc ? 1.0 : 2.0;
-    double* outp = p.partials + ((size_t)task * NT + tile) * (D + 2);
-    // (the points were staged by this wave itself: LDS is in order, no barrier needed)
     const double ac = xs[(xc + lc) * DP + D];   // alpha, staged with the points (0 past n)
-    double G[4], hk[4];
-    double g_os = 0.0, g_noise = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int a = 16 * ta + lq + 4 * g;
-      const bool ok = a < n && pc < n;
-      double d2 = 0.0;
-      for (int d = 0; d < D; ++d) {
-        const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
-        d2 = __builtin_fma(df, df, d2);
+      GH[t][g] = 0.0;
+      if (tiles_on[t]) {
+        const int a = 16 * ta + lq + 4 * g;
+        const bool ok = a < n && pc < n;
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
+          d2 = __builtin_fma(df, df, d2);
+        }
+        double k, h;
+        kernel_and_dfactor<KIND>(d2, exptab, k, h);
+        const double Gv = ok ? wgt * (xs[(xa + lq + 4 * g) * DP + D] * ac - kin[g]) : 0.0;
+        GH[t][g] = Gv * os * h;   // (os folded in: every lengthscale term carries it)
+        g_os = __builtin_fma(Gv, k, g_os);
+        if (a == pc) g_noise += Gv;
       }
-      double k, h;
-      kernel_and_dfactor<KIND>(d2, exptab, k, h);
-      const double Gv = ok ? wgt * (xs[(xa + lq + 4 * g) * DP + D] * ac - kin[g]) : 0.0;
-      G[g] = Gv * os;   // (os folded in: every lengthscale term carries it)
-      hk[g] = h;
-      g_os = __builtin_fma(Gv, k, g_os);
-      if (a == pc) g_noise += Gv;
     }
-    // lengthscales: d mll / d l_d ~ sum G os h delta_d^2 / l_d^3 with delta / l already in LDS: sum G os h (delta/l)^2 / l
-    for (int d = 0; d < D; ++d) {
-      double s = 0.0;
+  }
+  const int tile0 = tc0 * NB - tc0 * (tc0 - 1) / 2 + (ta0 - tc0);   // column-major index over the lower triangle of tiles
+  double* outp = p.partials + ((size_t)task * NT + tile0) * (D + 2);
+  // lengthscales: d mll / d l_d ~ sum G os h delta_d^2 / l_d^3 with delta / l already in LDS: sum G os h (delta/l)^2 / l
+  for (int d = 0; d < D; ++d) {
+    double sd = 0.0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
-        s = __builtin_fma(G[g] * hk[g], df * df, s);
+    for (int t = 0; t < 4; ++t) {
+      if (tiles_on[t]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double df = xs[(tiles_xa[t] + lq + 4 * g) * DP + d] - xs[(tiles_xc[t] + lc) * DP + d];
+          sd = __builtin_fma(GH[t][g], df * df, sd);
+        }
       }
-      const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
-      s = wave_sum_to_lane15(s * il);
-      if (lane == 63) outp[d] = s;
     }
-    g_os = wave_sum_to_lane15(g_os);
-    g_noise = wave_sum_to_lane15(g_noise);
-    if (lane == 63) {
-      outp[D] = g_os;        // = sum G k  (d K / d os = k)
-      outp[D + 1] = g_noise; // = tr G
+    const double il = d < 64 ? invl_s[d] : 1.0 / th[d];
+    sd = wave_sum_to_lane15(sd * il);
+    if (lane == 63) outp[d] = sd;
+  }
+  g_os = wave_sum_to_lane15(g_os);
+  g_noise = wave_sum_to_lane15(g_noise);
+  if (lane == 63) {
+    outp[D] = g_os;        // = sum G k  (d K / d os = k)
+    outp[D + 1] = g_noise; // = tr G
+  }
+  // the other tiles of the super-tile contribute through the slot above: their own slots are zero
+#pragma unroll
+  for (int t = 1; t < 4; ++t) {
+    if (tiles_on[t]) {
+      const int ta = tiles_ta[t], tc = tiles_tc[t];
+      const int tile = tc * NB - tc * (tc - 1) / 2 + (ta - tc);
+      double* o = p.partials + ((size_t)task * NT + tile) * (D + 2);
+      for (int e = lane; e < D + 2; e += 64) o[e] = 0.0;
     }
-  };
-  epilogue(ta0, tc0, 0, 32, k00);
-  if (ta1 < NB) epilogue(ta1, tc0, 16, 32, k10);
-  if (ta1 < NB && tc1 < NB) epilogue(ta1, tc1, 16, 48, k11);
-  if (!diag && tc1 < NB) epilogue(ta0, tc1, 0, 48, k01);
+  }
 }
 
 }  // namespace scaml
