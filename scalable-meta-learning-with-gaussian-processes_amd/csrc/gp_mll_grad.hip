@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
         const int a = 16 * ta + lq + 4 * g;
         const bool ok = a < n && pc < n;
         double d2 = 0.0;
-        for (int d = 0; d < D; ++d) {
+#pragma unroll 4
+        for (int d = 0; d < D; ++d) {   // (unrolled: the LDS reads of four dimensions are in flight together)
           const double df = xs[(xa + lq + 4 * g) * DP + d] - xs[(xc + lc) * DP + d];
           d2 = __builtin_fma(df, df, d2);
         }
