@@ -42,18 +42,56 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
   // rows above the strip are zero
   for (int r = lq; r < 16 * strip && r < N; r += 4)
     if (qc < N) Og[(size_t)r * N + qc] = 0.0;
+  // acc -= sum_{strip <= j < kb} L[kb, j] V_j.  One workgroup per task at T >= 256 means ONE wave per SIMD: nobody
+  // hides this wave's load latency, so the L row segments are fetched four tiles ahead -- across the end of a block
+  // row into the first tiles of the next -- and W_kb one block ahead (subst_accumulate looks one tile ahead).
+  LRowSeg q[4];
+  auto fetch4 = [&](int kbr, int jf) {   // tiles jf .. jf + 3 of block row kbr (zeros past the diagonal / the matrix)
+    const int arow = 16 * kbr + lc;
+    const bool arow_ok = kbr < NB && arow < n;
+    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
+    const bool rows_in = 16 * kbr + 16 <= n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jf + u;
+      if (kbr < NB && j < kbr) {
+        q[u] = load_lrow_seg(Lrow, 16 * j + 4 * lq, rows_in && (N & 1) == 0 && 16 * j + 16 <= n, arow_ok, n);
+      } else {
+        q[u].a[0] = q[u].a[1] = q[u].a[2] = q[u].a[3] = 0.0;
+      }
+    }
+  };
+  double wn[4];
+  auto fetch_w = [&](int kbn) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wn[m] = kbn < NB ? Wg[(size_t)kbn * 256 + lc * 16 + lq + 4 * m] : 0.0;
+  };
+  fetch_w(strip);
+  fetch4(strip + 1, strip);
   for (int kb = strip; kb < NB; ++kb) {
     d4_t acc;
+    double wc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = (kb == strip && lc == lq + 4 * g) ? 1.0 : 0.0;
-    const int arow = 16 * kb + lc;
-    const bool arow_ok = arow < n;
-    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    acc = subst_accumulate(acc, Lrow, arow_ok, 16 * kb + 16 <= n, n, (N & 1) == 0, Vs, strip, kb, lc, lq);
+    for (int g = 0; g < 4; ++g) { acc[g] = (kb == strip && lc == lq + 4 * g) ? 1.0 : 0.0; wc[g] = wn[g]; }
+    fetch_w(kb + 1);
+    for (int j0 = strip; j0 < kb; j0 += 4) {
+      LRowSeg cur[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cur[u] = q[u];
+      if (j0 + 4 < kb) fetch4(kb, j0 + 4); else fetch4(kb + 1, strip);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < kb) {   // (the strip's rows of later blocks are not written yet: no reading them, even times zero)
+          const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u].a[m], vb[4 * m * 16], acc, 0, 0, 1);
+        }
+      }
+    }
     d4_t v = {0.0, 0.0, 0.0, 0.0};
-    const double* wrow = Wg + (size_t)kb * 256 + lc * 16 + lq;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wrow[4 * m], acc[m], v, 0, 0, 0);
+    for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[m], acc[m], v, 0, 0, 0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = 16 * kb + lq + 4 * g;
