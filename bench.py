@@ -5,8 +5,9 @@ One "step" = one pass of the hot path over one batch of synthetic input: a singl
 scaml_gp_fit_fused_f64 over T = 256 meta-tasks x N = 256 points x D = 8, Matern-5/2 + ARD
 (BASELINE.json configs[2], the configuration the metric is quoted on), inputs resident in HBM.
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
-owns its own 256-task shard (weak scaling) and each step also all-reduces the summed marginal
-likelihood across ranks (the path's only exchange step).
+owns its own 256-task shard (weak scaling); the summed marginal likelihoods of all steps of the timed
+region are all-reduced across ranks in one collective at its end (the path's only exchange step,
+batched: a collective per step would take a CU from the next launch's one-per-CU workgroups).
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — algorithmic fp64 flops per launch / measured kernel duration vs the fp64 MFMA peak
@@ -149,17 +150,25 @@ def main():
     # allocates the output buffers once; every step rewrites them completely
     out = ops.gp_fit_fused(X, y, th, kind)
     total = args.warmup + args.steps
-    sums = torch.zeros(total, 1, dtype=torch.float64, device=device)
+    # Multi-GPU: the only coupling of the shards is the sum of the per-task MLLs (scamlgp/model.py:129-134 sums over
+    # tasks).  Every step writes its per-task values into its own row; ONE all-reduce per timed region carries the
+    # sums of all its steps ("batch several evaluations per collective").  A collective per step would
+    # put an RCCL workgroup on one of the 256 CUs the next launch's 256 one-per-CU workgroups need.
+    mll_rows = torch.zeros(total, T_PER_GPU, dtype=torch.float64, device=device) if distributed else None
     works = []
 
     def step(i):
-        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=True)   # the full dense L, zeros included, every step
         if distributed:
-            torch.sum(out["mll"], dim=0, keepdim=True, out=sums[i])
-            works.append(dist.all_reduce(sums[i], async_op=True))
+            out["mll"] = mll_rows[i]
+        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=True)   # the full dense L, zeros included, every step
+
+    def reduce_region(lo, hi):
+        if distributed:
+            sums = mll_rows[lo:hi].sum(1)
+            works.append((dist.all_reduce(sums, async_op=True), sums))
 
     def fence():
-        for w in works:
+        for w, _ in works:
             w.wait()
         works.clear()
         torch.cuda.synchronize()
@@ -169,6 +178,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    reduce_region(0, args.warmup)
     fence()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
@@ -177,6 +187,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     ev1.record()
+    reduce_region(args.warmup, total)   # inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launch stream only: avg duration per fused-fit launch
@@ -207,7 +218,7 @@ def main():
                 "workload": "configs[2]: 256 meta-tasks x 256 points x d=8, Matern-5/2 + ARD, per GPU "
                             "(fused K + jittered Cholesky + alpha + MLL, L stored)",
                 "tasks_per_gpu": T_PER_GPU, "points": N_POINTS, "dim": DIM, "kernel": "matern52",
-                "sharding": "task shards, one all-reduce of the summed MLL per step" if distributed else "single GPU",
+                "sharding": "task shards, one all-reduce of the per-step MLL sums per timed region" if distributed else "single GPU",
                 "all_tasks_psd": ok,
             },
             "roofline": {
