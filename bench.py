@@ -4,10 +4,20 @@
 One "step" = one pass of the hot path over one batch of synthetic input: a single launch of
 scaml_gp_fit_fused_f64 over T = 256 meta-tasks x N = 256 points x D = 8, Matern-5/2 + ARD
 (BASELINE.json configs[2], the configuration the metric is quoted on), inputs resident in HBM.
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) every rank
-owns its own 256-task shard (weak scaling); the summed marginal likelihoods of all steps of the timed
-region are all-reduced across ranks in one collective at its end (the path's only exchange step,
-batched: a collective per step would take a CU from the next launch's one-per-CU workgroups).
+``--step fit+grad`` adds the analytic hyper-gradient (scaml_mll_backward_f64) to every step: one
+L-BFGS evaluation of the meta-fit (the reference's HOT LOOP #2, scamlgp/utils.py:175).
+
+Multi-GPU (BASELINE.json configs[3]: task shards + "RCCL all-reduce of the MLL hyper-gradient"):
+``python bench.py --gpus N`` starts N fresh child ranks itself (torch.distributed.run, one rank per
+GPU over RCCL); the driver may also launch the ranks directly.  Every rank owns its own 256-task
+shard (weak scaling; 1024 tasks = 4 GPUs' worth).  The shards' only coupling is a sum over tasks
+(scamlgp/model.py:129-134): ONE all-reduce per timed region carries the fused buffer
+    [ sum_t MLL_t of every step of the region  ||  sum_t dMLL_t/dtheta (D + 2) ]
+where the gradient sum comes from one fit + backward evaluation over the shard that closes the region
+(with ``--step fit+grad``: from every step).  The collective is batched on purpose: a collective per
+step would put an RCCL workgroup on one of the 256 CUs the next launch's one-per-CU workgroups need.
+The same region (steps + closing backward + reduce) is timed at every N, N = 1 included, so the
+per-N values are comparable.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — algorithmic fp64 flops per launch / measured kernel duration vs the fp64 MFMA peak
@@ -19,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +48,13 @@ def algorithmic_flops_per_task(N: int, D: int, matern: bool) -> float:
     + 2 N^2 [two TRSV] + 3 N [quad, logdet]; c_k = 8 Matern-5/2, 2 RBF; FMA = 2."""
     ck = 8 if matern else 2
     return N ** 3 / 3.0 + N * (N + 1) / 2.0 * (4 * D + ck) + 2.0 * N * N + 3.0 * N
+
+
+def algorithmic_backward_flops_per_task(N: int, D: int, matern: bool) -> float:
+    """SURVEY.md §8(d) "Backward add-on": ~N^3 (L^-1: N^3/3, K^-1 = L^-T L^-1 lower half: N^3/3 ... the survey
+    rounds to N^3; counted here as 2 N^3 / 3) + N^2 (4D + c) for G o dK/dtheta."""
+    ck = 8 if matern else 2
+    return 2.0 * N ** 3 / 3.0 + float(N) * N * (4 * D + ck)
 
 
 def algorithmic_bytes_per_task(N: int, D: int) -> float:
@@ -73,31 +92,66 @@ def make_inputs(rank: int, device):
     return (X, y, th), (X.to(device), y.to(device), th.to(device))
 
 
-def cpu_baseline(host_inputs, budget_s: float = 8.0):
-    """Time the oracle on the host cores over a bounded sample of the bench workload, two ways:
-    the reference's shape of work — a per-task Python loop (scamlgp/model.py:176-188), one dense
-    Cholesky per task — and the same arithmetic as one batched torch.linalg call.  The faster of
-    the two is reported as the baseline value; both are named in `sample`."""
+# ---- CPU baseline ------------------------------------------------------------------------------------
+def _pool_init():
+    # worker of the process-pool leg: a fresh child that never touches the GPU, one thread
+    # (the reference's deployment shape: scamlgp/benchmarking/local_runner.py:107-108, 174-181)
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    import torch
+
+    torch.set_num_threads(1)
+
+
+def _pool_work(args):
+    import torch
+    from oracle import gp_oracle as O
+
+    X, y, th, reps = args
+    X, y, th = torch.from_numpy(X), torch.from_numpy(y), torch.from_numpy(th)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        O.gp_fit_stack_loop(X, y, th, O.KIND_MATERN52)
+    return reps * X.shape[0], time.perf_counter() - t0
+
+
+def cpu_baseline(host_inputs, budget_s: float = 4.0):
+    """Time the oracle on the host cores over a bounded sample of the bench workload (~25 s in all):
+      * the reference's shape of work -- a per-task Python loop (scamlgp/model.py:176-188), one dense Cholesky per
+        task -- at 1, 8, 32 and all torch threads (256 x 256 matrices do not scale to 128 threads);
+      * the same arithmetic as one batched torch.linalg call (64-task chunks) at the best of those settings;
+      * the reference's own deployment shape: P = min(64, cores) single-thread worker processes
+        (scamlgp/benchmarking/local_runner.py:107-108, 174-181), each looping over its own tasks.
+    The best rate is the reported value; every leg is named in `sample`."""
+    import multiprocessing as mp
+
     import torch
     from oracle import gp_oracle as O
 
     X, y, th = host_inputs
-    cores = torch.get_num_threads()
+    cores = os.cpu_count() or torch.get_num_threads()
+    all_threads = torch.get_num_threads()
     O.gp_fit_stack_loop(X[:2], y[:2], th[:2], O.KIND_MATERN52)  # warm-up
-    done = 0
-    t0 = time.perf_counter()
-    while True:
-        lo = done % T_PER_GPU
-        hi = min(lo + 8, T_PER_GPU)
-        O.gp_fit_stack_loop(X[lo:hi], y[lo:hi], th[lo:hi], O.KIND_MATERN52)
-        done += hi - lo
-        el = time.perf_counter() - t0
-        if el > budget_s or done >= 4 * T_PER_GPU:
-            break
-    loop_rate = done / el
+    legs = []
+    best_threads, best_loop = 1, 0.0
+    for nt in sorted({1, min(8, cores), min(32, cores), all_threads}):
+        torch.set_num_threads(nt)
+        O.gp_fit_stack_loop(X[:2], y[:2], th[:2], O.KIND_MATERN52)
+        done, t0 = 0, time.perf_counter()
+        while True:
+            lo = done % T_PER_GPU
+            hi = min(lo + 8, T_PER_GPU)
+            O.gp_fit_stack_loop(X[lo:hi], y[lo:hi], th[lo:hi], O.KIND_MATERN52)
+            done += hi - lo
+            el = time.perf_counter() - t0
+            if el > budget_s * 0.6 or done >= 4 * T_PER_GPU:
+                break
+        rate = done / el
+        legs.append((f"per-task loop, {nt} thread{'s' if nt > 1 else ''}", rate, nt, f"{done} tasks in {el:.1f} s"))
+        if rate > best_loop:
+            best_loop, best_threads = rate, nt
+    torch.set_num_threads(best_threads)
     O.gp_fit_stack_batched(X[:8], y[:8], th[:8], O.KIND_MATERN52)  # warm-up
-    chunk, done_b = 64, 0
-    t0 = time.perf_counter()
+    chunk, done_b, t0 = 64, 0, time.perf_counter()
     while True:
         lo = done_b % T_PER_GPU
         O.gp_fit_stack_batched(X[lo:lo + chunk], y[lo:lo + chunk], th[lo:lo + chunk], O.KIND_MATERN52)
@@ -105,10 +159,78 @@ def cpu_baseline(host_inputs, budget_s: float = 8.0):
         el_b = time.perf_counter() - t0
         if el_b > budget_s or done_b >= 8 * T_PER_GPU:
             break
-    batched_rate = done_b / el_b
-    return dict(value=max(loop_rate, batched_rate), unit="task-posteriors/s", cores=cores, kind="port",
-                sample=(f"torch-fp64 oracle on the bench workload: per-task loop {done} tasks in {el:.1f} s = {loop_rate:.1f}/s; "
-                        f"batched torch.linalg (64-task chunks) {done_b} tasks in {el_b:.1f} s = {batched_rate:.1f}/s"))
+    legs.append((f"batched torch.linalg (64-task chunks), {best_threads} threads", done_b / el_b, best_threads, f"{done_b} tasks in {el_b:.1f} s"))
+    torch.set_num_threads(all_threads)
+    # process pool: fresh children (spawn), no GPU, one thread each
+    P = max(1, min(64, cores))
+    try:
+        ctx = mp.get_context("spawn")
+        per = 4  # tasks per worker and repetition
+        Xn, yn, thn = X.numpy(), y.numpy(), th.numpy()
+
+        def jobs(reps):
+            return [(Xn[(w * per) % T_PER_GPU:(w * per) % T_PER_GPU + per], yn[(w * per) % T_PER_GPU:(w * per) % T_PER_GPU + per],
+                     thn[(w * per) % T_PER_GPU:(w * per) % T_PER_GPU + per], reps) for w in range(P)]
+
+        with ctx.Pool(P, initializer=_pool_init) as pool:
+            warm = pool.map(_pool_work, jobs(1), chunksize=1)  # imports + first call
+            per_rep = max(sum(t for _, t in warm) / len(warm), 1e-4)
+            reps = max(1, min(200, int(budget_s / per_rep)))
+            t0 = time.perf_counter()
+            res = pool.map(_pool_work, jobs(reps), chunksize=1)
+            el_p = time.perf_counter() - t0
+        done_p = sum(n for n, _ in res)
+        legs.append((f"{P} single-thread worker processes (per-task loop each)", done_p / el_p, P, f"{done_p} tasks in {el_p:.1f} s"))
+    except Exception as e:  # a box that cannot spawn workers still reports the in-process legs
+        legs.append((f"process pool failed: {type(e).__name__}: {e}", 0.0, 0, ""))
+    best = max(legs, key=lambda l: l[1])
+    sample = "torch-fp64 oracle on the bench workload (T=256 stack, N=256, D=8, Matern-5/2); " + "; ".join(
+        f"{name}: {what} = {rate:.1f}/s" for name, rate, _, what in legs) + f"; reported: {best[0]}"
+    return dict(value=best[1], unit="task-posteriors/s", cores=best[2], kind="port", sample=sample, host_cores=cores)
+
+
+# ---- parent: start the ranks ---------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: build once, then start N fresh child ranks
+    (no GPU call has happened in this process) and relay their output and exit code."""
+    import __graft_entry__ as entry
+
+    entry.build()   # once, here: the ranks then find an up-to-date library and do not race writing it
+    import torch
+
+    have = torch.cuda.device_count()   # (does not initialise the GPU)
+    env = dict(os.environ)
+    if have < args.gpus and env.get("SCAML_BENCH_REHEARSAL") != "1":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {have} visible "
+                         "(SCAML_BENCH_REHEARSAL=1 rehearses the multi-rank control flow on one GPU; its numbers mean nothing)\n")
+        return 2
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SCAML_BENCH_PARENT_BUILT"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--step", args.step]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        print(line, flush=True)
+    if res.returncode != 0:
+        return res.returncode
+    return 0 if line is not None else 1
 
 
 def main():
@@ -116,56 +238,72 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--step", choices=("fit", "fit+grad"), default="fit",
+                    help="fit: the metric's step (K + Cholesky + solves + MLL); fit+grad: + the hyper-gradient every step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
 
-    entry.build()
-    from scamlgp_amd import ops
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # SCAML_BENCH_REHEARSAL=1: rehearse the multi-rank control flow on ONE GPU (all ranks on cuda:0, gloo instead of
     # RCCL, which refuses two ranks on one device).  Numbers from such a run mean nothing; it exists so that the
     # barrier / all-reduce / max-over-ranks logic can be exercised on a one-GPU box.
     rehearsal = os.environ.get("SCAML_BENCH_REHEARSAL") == "1"
     device = torch.device("cuda", 0 if rehearsal else local_rank)
-    torch.cuda.set_device(device)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        # one rank builds (a no-op when the parent launcher or an earlier run already did), the others wait
+        dist.init_process_group("gloo" if rehearsal else "nccl", **({} if rehearsal else {"device_id": device}))
+        if local_rank == 0:
+            entry.build()
+        torch.cuda.set_device(device)
+        dist.barrier()
+    entry.build()
+    torch.cuda.set_device(device)
+    from scamlgp_amd import ops
 
     host_inputs, (X, y, th) = make_inputs(rank, device)
     kind = ops.KIND_MATERN52
+    with_grad = args.step == "fit+grad"
     # allocates the output buffers once; every step rewrites them completely
     out = ops.gp_fit_fused(X, y, th, kind)
+    out_g = ops.gp_fit_fused(X, y, th, kind, want_linv=True)   # the evaluation with a gradient also keeps the diagonal-block inverses
+    gws = ops.mll_backward_workspace(T_PER_GPU, N_POINTS, DIM, device)
     total = args.warmup + args.steps
-    # Multi-GPU: the only coupling of the shards is the sum of the per-task MLLs (scamlgp/model.py:129-134 sums over
-    # tasks).  Every step writes its per-task values into its own row; ONE all-reduce per timed region carries the
-    # sums of all its steps ("batch several evaluations per collective").  A collective per step would
-    # put an RCCL workgroup on one of the 256 CUs the next launch's 256 one-per-CU workgroups need.
-    mll_rows = torch.zeros(total, T_PER_GPU, dtype=torch.float64, device=device) if distributed else None
+    # Every step writes its per-task MLLs into its own row; the region's ONE all-reduce carries
+    # [sum_t MLL_t per step || sum_t dMLL_t/dtheta] (one fused buffer, several evaluations per collective).
+    mll_rows = torch.zeros(total, T_PER_GPU, dtype=torch.float64, device=device)
+    grad_acc = torch.zeros(DIM + 2, dtype=torch.float64, device=device)
     works = []
 
     def step(i):
-        if distributed:
-            out["mll"] = mll_rows[i]
-        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=True)   # the full dense L, zeros included, every step
+        o = out_g if with_grad else out
+        o["mll"] = mll_rows[i]
+        ops.gp_fit_fused(X, y, th, kind, out=o, zero_upper=True, want_linv=with_grad)   # the full dense L, zeros included, every step
+        if with_grad:
+            grad_acc.add_(ops.mll_backward(X, th, kind, o["L"], o["Linv_diag"], o["alpha"], workspace=gws).sum(0))
 
-    def reduce_region(lo, hi):
+    def close_region(lo, hi):
+        """The evaluation that ends a region: hyper-gradient of the last step's factors (unless every step had one),
+        then the fused buffer goes through the one collective."""
+        if not with_grad:
+            ops.gp_fit_fused(X, y, th, kind, out=out_g, zero_upper=True, want_linv=True)
+            grad_acc.copy_(ops.mll_backward(X, th, kind, out_g["L"], out_g["Linv_diag"], out_g["alpha"], workspace=gws).sum(0))
+        buf = torch.cat([mll_rows[lo:hi].sum(1), grad_acc])
         if distributed:
-            sums = mll_rows[lo:hi].sum(1)
-            works.append((dist.all_reduce(sums, async_op=True), sums))
+            works.append((dist.all_reduce(buf, async_op=True), buf))
+        return buf
 
     def fence():
         for w, _ in works:
@@ -178,8 +316,11 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    reduce_region(0, args.warmup)
+    close_region(0, args.warmup)
+    grad_acc.zero_()
     fence()
+    # the dominant kernel's launches are timed with HIP events on the stream they are launched on (torch's current
+    # stream: ops passes torch.cuda.current_stream() across the C ABI)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -187,19 +328,22 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     ev1.record()
-    reduce_region(args.warmup, total)   # inside the timed region
+    reduced = close_region(args.warmup, total)   # inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launch stream only: avg duration per fused-fit launch
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launch stream only: avg duration of one step's launches
 
     if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ok = not bool(out["info"].any().item())
+    reduced = reduced.cpu()
 
     if rank == 0:
         flops = algorithmic_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
+        if with_grad:
+            flops += algorithmic_backward_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         res = {
             "metric": "task-posteriors/sec (K+chol+solve+MLL) at T=256,N=256; 1/2/4/8 GPU",
@@ -216,15 +360,21 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "configs[2]: 256 meta-tasks x 256 points x d=8, Matern-5/2 + ARD, per GPU "
-                            "(fused K + jittered Cholesky + alpha + MLL, L stored)",
+                            "(fused K + jittered Cholesky + alpha + MLL, L stored)"
+                            + (" + analytic MLL hyper-gradient every step" if with_grad else ""),
+                "step": args.step,
                 "tasks_per_gpu": T_PER_GPU, "points": N_POINTS, "dim": DIM, "kernel": "matern52",
-                "sharding": "task shards, one all-reduce of the per-step MLL sums per timed region" if distributed else "single GPU",
+                "sharding": ("task shards (configs[3] layout: 1024 tasks = 4 such shards), " if distributed else "single GPU, ")
+                            + "one fused all-reduce [sum MLL per step || sum dMLL/dtheta] per timed region"
+                            + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal and distributed else ""),
                 "all_tasks_psd": ok,
+                "reduced_mll_sum_last_step": float(reduced[args.steps - 1]),
+                "reduced_grad_norm": float(reduced[args.steps:].norm()),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": recorded_pmc_traffic(),
-                "kernel": "gp_fit_fused_kernel<16,7,matern52>",
+                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": recorded_pmc_traffic() if not with_grad else None,
+                "kernel": "gp_fit_fused_kernel<16,7,matern52>" + (" + gp_linv_kernel + gp_mll_grad_kernel" if with_grad else ""),
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": algorithmic_bytes_per_task(N_POINTS, DIM) * T_PER_GPU,

@@ -389,7 +389,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   {
     __syncthreads();  // previous attempt done with region A
     // (sqrt 2 folded into the scaling: the cross term of the squared distance then needs no factor 2)
-    if (!from_matrix && tid < D) invl[tid] = 1.4142135623730951 / th[tid];
+    if (!from_matrix)   // strided: the workgroup may have fewer threads than D (128 threads at N <= 32, D up to ~588)
+      for (int d = tid; d < D; d += NTHREADS) invl[d] = 1.4142135623730951 / th[d];
     if (tid < 2) flagp[tid] = 0;
     if (tid < 6 * NB) flagW[tid] = 0;
     exp2_table_init(exptab, tid);

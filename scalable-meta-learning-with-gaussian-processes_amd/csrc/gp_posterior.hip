@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
   const double ys = p.y_std ? p.y_std[task] : 1.0;
 
   exp2_table_init(exptab, tid);
-  if (tid < D) invl[tid] = 1.0 / th[tid];
+  for (int d = tid; d < D; d += blockDim.x) invl[d] = 1.0 / th[d];   // strided: D may exceed the 64 .. 256 threads
   for (int r = tid; r < NP; r += blockDim.x) alpha_s[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
   __syncthreads();
   if (p.x_in_lds) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   const int qc = 16 * strip + lc;   // this lane's query point
 
   exp2_table_init(exptab, tid);
-  if (tid < D) invl[tid] = 1.0 / th[tid];
+  for (int d = tid; d < D; d += blockDim.x) invl[d] = 1.0 / th[d];   // strided: D may exceed the 64 .. 256 threads
   if (tid < 32) red[tid] = 0.0;
   for (int r = tid; r < NP; r += blockDim.x) alpha_s[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
   __syncthreads();

@@ -95,9 +95,19 @@ struct Module {
   }
 };
 
+// One Module per device ordinal: hipModuleLoadData loads the code object into the CURRENT device's context and the
+// hipFunction_t handles are only valid there, so a process that works on several GPUs (cuda:0, then cuda:1) gets one
+// lazily loaded copy per device.  Every entry point runs on the current device (hipGetDevice), which therefore has
+// to be the device the pointers and the stream belong to.
+constexpr int kMaxDevices = 64;
 Module& module() {
-  static Module m;
-  return m;
+  static std::mutex mu;
+  static Module* mods[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!mods[dev]) mods[dev] = new Module();
+  return *mods[dev];
 }
 
 size_t fit_lds_bytes(int nb, int wu, int D) {
@@ -113,7 +123,7 @@ size_t fit_lds_bytes(int nb, int wu, int D) {
 
 extern "C" {
 
-int scaml_version(void) { return 300; }  // 0.3.0
+int scaml_version(void) { return 400; }  // 0.4.0 = 10000 * 0 + 100 * 4 + 0
 const char* scaml_last_error(void) { return g_last_error; }
 int scaml_fit_max_n(void) { return 256; }
 

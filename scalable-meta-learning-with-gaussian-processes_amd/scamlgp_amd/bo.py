@@ -1,48 +1,98 @@
-"""A thin Bayesian-optimisation driver around the GPU path — the caller of the hot path in the
+"""A thin Bayesian-optimisation driver around the GPU path -- the caller of the hot path in the
 reference is blackboxopt's ``SingleObjectiveBOTorchOptimizer`` (absent here); this module restates the
 two things ``scamlgp/optimizer.py`` does with the model:
 
-  report():  rebuild ScaMLGP on all target evaluations, warm-started from the previous kernel
-             hyper-parameters, and refit weights + hyper-parameters (optimizer.py:156-185)
+  report():  rebuild ScaMLGP on all target evaluations, handing the previous model's likelihood and kernel
+             modules back in (warm start), and refit weights + hyper-parameters (optimizer.py:156-185)
   generate_evaluation_specification():  maximise the acquisition function (UCB with beta = 9 by
              default, utils.py:215-224) over the unit-cube search space.
 
-The acquisition optimiser evaluates ALL candidates in one batched posterior call (raw Sobol-free
-random candidates, then a few rounds of local Gaussian perturbation around the incumbents) rather
-than botorch's multi-start L-BFGS-B, which issues one posterior call per gradient step."""
+The acquisition optimiser follows botorch's ``optimize_acqf`` recipe -- ``raw_samples`` random candidates, ``num_restarts``
+initial conditions drawn from them (the best one plus a Boltzmann sample of the rest), a quasi-Newton ascent from every
+start, best end point wins -- but runs all starts in lockstep: one batched L-BFGS whose every objective evaluation is ONE
+batched posterior call over the starts and their central-difference stencils (the HIP posterior has no input-gradient
+kernel), instead of one posterior call per gradient step and start."""
 from __future__ import annotations
 
-from typing import Callable, Dict, Hashable, Optional
+from typing import Callable, Dict, Hashable, Optional, Tuple
 
 import torch
 
-from .model import KernelSpec, ScaMLGP, SourceGP
+from . import hyper
+from .model import ScaMLGP, SourceGP
 from .utils import ExpectedImprovement, UpperConfidenceBound, optimize_marginal_likelihood
+
+
+def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samples: int = 1024, num_restarts: int = 10,
+                  max_iter: int = 30, generator: Optional[torch.Generator] = None, fd_step: float = 1e-4,
+                  eta: float = 2.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Maximise ``af`` over [0, 1]^dim by multi-start quasi-Newton ascent; returns (x_best (dim,), af(x_best)).
+    Candidates stay in the cube through x = sigmoid(z); gradients are central differences in x."""
+    cand = torch.rand(raw_samples, dim, dtype=torch.float64, generator=generator)
+    vals = af(cand).detach().cpu()
+    R = min(num_restarts, raw_samples)
+    best0 = int(vals.argmax())
+    picks = [best0]
+    if R > 1:
+        # botorch initialize_q_batch: P(i) ~ exp(eta * standardised value), the maximiser always included
+        z = (vals - vals.mean()) / vals.std().clamp_min(1e-12)
+        pr = torch.exp(eta * (z - z.max()))
+        pr[best0] = 0.0
+        if float(pr.sum()) > 0:
+            k = min(R - 1, int((pr > 0).sum()))
+            picks += torch.multinomial(pr, k, replacement=False, generator=generator).tolist()
+    x0 = cand[picks].clamp(1e-6, 1.0 - 1e-6)
+    R = x0.shape[0]
+    eye = torch.eye(dim, dtype=torch.float64)
+
+    def fun(zv: torch.Tensor):
+        x = torch.sigmoid(zv.cpu())
+        xp = (x.unsqueeze(1) + fd_step * eye).clamp(0.0, 1.0)      # (R, dim, dim)
+        xm = (x.unsqueeze(1) - fd_step * eye).clamp(0.0, 1.0)
+        v = af(torch.cat([x, xp.reshape(-1, dim), xm.reshape(-1, dim)])).detach().cpu()
+        f = v[:R]
+        dx = (xp - xm).diagonal(dim1=1, dim2=2)
+        g = (v[R:R + R * dim].reshape(R, dim) - v[R + R * dim:].reshape(R, dim)) / dx
+        return -f, -g * x * (1.0 - x)
+
+    res = hyper.batched_lbfgs(fun, torch.log(x0) - torch.log1p(-x0), max_iter=max_iter, gtol=1e-6)
+    xs = torch.sigmoid(res.x)
+    fin = torch.where(torch.isfinite(res.f), -res.f, torch.full_like(res.f, -float("inf")))
+    j = int(fin.argmax())
+    if float(fin[j]) >= float(vals[best0]):
+        return xs[j], fin[j]
+    return cand[best0], vals[best0]
 
 
 class ScaMLGPBOLoop:
     def __init__(self, source_gps: Dict[Hashable, SourceGP], dim: int, acquisition: str = "ucb", beta: float = 9.0,
-                 num_restarts_log_likelihood: int = 5, raw_samples: int = 1024, refine_rounds: int = 2,
-                 covar_module: Optional[KernelSpec] = None, seed: Optional[int] = None):
+                 num_restarts_log_likelihood: int = 5, raw_samples: int = 1024, num_restarts: int = 10, af_max_iter: int = 30,
+                 gp_likelihood: Optional[hyper.GaussianLikelihood] = None, gp_kernel: Optional[hyper.ScaleKernel] = None,
+                 seed: Optional[int] = None):
         self.source_gps, self.dim = source_gps, dim
         self.acquisition, self.beta = acquisition, beta
-        self.num_restarts = num_restarts_log_likelihood
-        self.raw_samples, self.refine_rounds = raw_samples, refine_rounds
-        self.covar_module = covar_module
+        self.num_restarts_log_likelihood = num_restarts_log_likelihood
+        self.raw_samples, self.num_restarts, self.af_max_iter = raw_samples, num_restarts, af_max_iter
         self.gen = torch.Generator().manual_seed(0 if seed is None else seed)
         self.X = torch.empty(0, dim, dtype=torch.float64)
         self.Y = torch.empty(0, 1, dtype=torch.float64)
-        self.model = ScaMLGP(self.X, self.Y, source_gps, covar_module=covar_module)
+        # scamlgp/optimizer.py:142-148: the model before any evaluation (prior only)
+        self.model = ScaMLGP(self.X, self.Y, source_gps, likelihood=gp_likelihood, covar_module=gp_kernel)
 
     def report(self, x: torch.Tensor, y: float) -> None:
         self.X = torch.cat([self.X, torch.as_tensor(x, dtype=torch.float64).reshape(1, -1)], 0)
         self.Y = torch.cat([self.Y, torch.tensor([[float(y)]], dtype=torch.float64)], 0)
-        prev = self.model
-        self.model = ScaMLGP(self.X, self.Y, self.source_gps, covar_module=self.covar_module)
-        self.model.raw_theta = prev.raw_theta.clone()   # kernel / likelihood are re-used (optimizer.py:180-181);
-        optimize_marginal_likelihood(self.model, self.num_restarts)  # the weights restart from 1/T (model.py:319-322)
+        # scamlgp/optimizer.py:176-185, same call sequence: the fitted modules go back in, the weights restart at 1/T
+        self.model = ScaMLGP(
+            self.X,
+            self.Y,
+            self.source_gps,
+            likelihood=self.model.likelihood,
+            covar_module=self.model.covar_module,
+        )
+        optimize_marginal_likelihood(self.model, self.num_restarts_log_likelihood)
 
-    def _acquisition(self) -> Callable[[torch.Tensor], torch.Tensor]:
+    def acquisition_function(self) -> Callable[[torch.Tensor], torch.Tensor]:
         if self.acquisition == "ei":
             if self.Y.numel() == 0:
                 raise ValueError("EI needs at least one evaluation")
@@ -50,17 +100,9 @@ class ScaMLGPBOLoop:
         return UpperConfidenceBound(self.model, self.beta)
 
     def suggest(self) -> torch.Tensor:
-        af = self._acquisition()
-        cand = torch.rand(self.raw_samples, self.dim, dtype=torch.float64, generator=self.gen)
-        vals = af(cand).cpu()
-        for r in range(self.refine_rounds):
-            top = cand[vals.topk(min(16, len(vals))).indices]
-            scale = 0.05 / (r + 1)
-            local = (top.repeat_interleave(32, 0) + scale * torch.randn(top.shape[0] * 32, self.dim, dtype=torch.float64,
-                                                                          generator=self.gen)).clamp(0.0, 1.0)
-            lv = af(local).cpu()
-            cand, vals = torch.cat([cand, local]), torch.cat([vals, lv])
-        return cand[vals.argmax()]
+        self.model.eval()
+        x, _ = optimize_acqf(self.acquisition_function(), self.dim, self.raw_samples, self.num_restarts, self.af_max_iter, self.gen)
+        return x
 
     def run(self, objective: Callable[[torch.Tensor], float], n_steps: int):
         for _ in range(n_steps):

@@ -173,6 +173,125 @@ def target_gp_spec() -> HyperSpec:
                      Interval(1e-8, 1e-2), LogNormalPrior(-8.0, 2.0), 1e-3)
 
 
+# --- module-like parameter holders (what the reference hands around as `likelihood` / `covar_module`) ---------
+# The reference passes gpytorch modules: GaussianLikelihood(noise_prior, noise_constraint) and
+# ScaleKernel(RBFKernel | MaternKernel(ard_num_dims, lengthscale_prior, lengthscale_constraint), outputscale_prior,
+# outputscale_constraint) (scamlgp/model.py:25-105), and re-uses the fitted ones of the previous model when it
+# rebuilds ScaMLGP (scamlgp/optimizer.py:176-183).  These classes carry the same state -- constraint, prior and
+# the current (raw) value -- under the same attribute names, without gpytorch; the arithmetic stays in the kernels.
+class _Param:
+    """One constrained parameter group: raw tensor + Interval + prior."""
+
+    def __init__(self, constraint: Interval, prior, value):
+        self.constraint, self.prior = constraint, prior
+        self.raw = constraint.inverse_transform(torch.as_tensor(value, dtype=torch.float64))
+
+    @property
+    def value(self) -> torch.Tensor:
+        return self.constraint.transform(self.raw)
+
+    def set(self, value) -> None:
+        self.raw = self.constraint.inverse_transform(torch.as_tensor(value, dtype=torch.float64).to(self.raw.device))
+
+    def to(self, device) -> None:
+        self.raw = self.raw.to(device)
+
+
+class GaussianLikelihood:
+    """Homoskedastic noise sigma^2 (scamlgp/model.py:25-33): ``.noise``, ``.raw_noise``, ``.noise_prior``,
+    ``.raw_noise_constraint``."""
+
+    def __init__(self, noise_prior=None, noise_constraint: Optional[Interval] = None, initial_value: float = 1e-3):
+        self._p = _Param(noise_constraint or Interval(1e-8, 1e-2), noise_prior or LogNormalPrior(-8.0, 2.0), initial_value)
+
+    noise = property(lambda self: self._p.value, lambda self, v: self._p.set(v))
+    raw_noise = property(lambda self: self._p.raw)
+    noise_prior = property(lambda self: self._p.prior)
+    raw_noise_constraint = property(lambda self: self._p.constraint)
+
+    def to(self, device):
+        self._p.to(device)
+        return self
+
+
+class _BaseKernel:
+    kind = 0
+
+    def __init__(self, ard_num_dims: int = 1, lengthscale_prior=None, lengthscale_constraint: Optional[Interval] = None,
+                 initial_value=0.5):
+        self.ard_num_dims = int(ard_num_dims)
+        init = torch.as_tensor(initial_value, dtype=torch.float64).expand(self.ard_num_dims).clone()
+        self._p = _Param(lengthscale_constraint or Interval(1e-4, 1e2), lengthscale_prior or GammaPrior(3.0, 6.0), init)
+
+    lengthscale = property(lambda self: self._p.value, lambda self, v: self._p.set(v))
+    raw_lengthscale = property(lambda self: self._p.raw)
+    lengthscale_prior = property(lambda self: self._p.prior)
+    raw_lengthscale_constraint = property(lambda self: self._p.constraint)
+
+
+class RBFKernel(_BaseKernel):
+    """k = exp(-r^2 / 2), ARD (the reference's default base kernel, scamlgp/model.py:168-171, 292-297)."""
+    kind = 0
+
+
+class MaternKernel(_BaseKernel):
+    """Matern nu = 5/2, ARD (gpytorch MaternKernel's default nu)."""
+    kind = 1
+    nu = 2.5
+
+
+class ScaleKernel:
+    """outputscale * base_kernel (scamlgp/model.py:44-70, 87-105)."""
+
+    def __init__(self, base_kernel: _BaseKernel, outputscale_prior=None, outputscale_constraint: Optional[Interval] = None,
+                 initial_value: float = 1.0):
+        self.base_kernel = base_kernel
+        self._p = _Param(outputscale_constraint or Interval(1e-4, 1e2), outputscale_prior or GammaPrior(2.0, 0.15), initial_value)
+
+    outputscale = property(lambda self: self._p.value, lambda self, v: self._p.set(v))
+    raw_outputscale = property(lambda self: self._p.raw)
+    outputscale_prior = property(lambda self: self._p.prior)
+    raw_outputscale_constraint = property(lambda self: self._p.constraint)
+    kind = property(lambda self: self.base_kernel.kind)
+
+    def to(self, device):
+        self._p.to(device)
+        self.base_kernel._p.to(device)
+        return self
+
+
+def get_default_likelihood() -> GaussianLikelihood:
+    """scamlgp/model.py:25-33 ``_get_default_likelihood``."""
+    return GaussianLikelihood(LogNormalPrior(-8.0, 2.0), Interval(1e-8, 1e-2), 1e-3)
+
+
+def get_kernel_source_gp(base_kernel=RBFKernel, ard_num_dims: int = 1) -> ScaleKernel:
+    """scamlgp/model.py:36-70 ``_get_kernel_source_gp``: the priors of botorch's SingleTaskGP."""
+    return ScaleKernel(base_kernel(ard_num_dims, GammaPrior(3.0, 6.0), Interval(1e-4, 1e2), 0.5),
+                       GammaPrior(2.0, 0.15), Interval(1e-4, 1e2), 1.0)
+
+
+def get_default_kernel(base_kernel=RBFKernel, ard_num_dims: int = 1) -> ScaleKernel:
+    """scamlgp/model.py:73-105 ``_get_default_kernel`` (target GP: broad log-normal priors)."""
+    return ScaleKernel(base_kernel(ard_num_dims, LogNormalPrior(0.5, 1.5), Interval(1e-4, 1e2), 1.0),
+                       LogNormalPrior(-2.0, 3.0), Interval(1e-4, 1e2), 0.1)
+
+
+def spec_from_modules(likelihood: GaussianLikelihood, covar_module: ScaleKernel) -> HyperSpec:
+    """The constraints / priors of a (likelihood, covar_module) pair as a HyperSpec; the init values are the
+    modules' CURRENT values (lengthscales: their mean -- HyperSpec inits are per group)."""
+    bk = covar_module.base_kernel
+    return HyperSpec(bk.raw_lengthscale_constraint, bk.lengthscale_prior, float(bk.lengthscale.mean()),
+                     covar_module.raw_outputscale_constraint, covar_module.outputscale_prior, float(covar_module.outputscale),
+                     likelihood.raw_noise_constraint, likelihood.noise_prior, float(likelihood.noise))
+
+
+def modules_from_spec(spec: HyperSpec, kind: int, D: int):
+    bk = (MaternKernel if kind == 1 else RBFKernel)(D, spec.ls_prior, spec.ls_constraint, spec.ls_init)
+    return (GaussianLikelihood(spec.noise_prior, spec.noise_constraint, spec.noise_init),
+            ScaleKernel(bk, spec.os_prior, spec.os_constraint, spec.os_init))
+
+
 # --- batched L-BFGS -----------------------------------------------------------------------------
 @dataclass
 class LBFGSResult:

@@ -16,11 +16,13 @@ by the eval-mode value the reference happens to compute (``scamlgp/utils.py:176-
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass
 from typing import Dict, Hashable, List, Optional, Sequence, Tuple
 
 import torch
 
+from . import dist as sdist
 from . import hyper, ops
 from ._lib import KIND_MATERN52, KIND_RBF
 
@@ -47,25 +49,49 @@ class SupervisedDataset:
 
 
 def validate_meta_data(meta_data: Dict[Hashable, SupervisedDataset]) -> None:
-    """scamlgp/utils.py:112-136 (same checks, same messages)."""
-    if len(meta_data) == 0:
+    """The checks of scamlgp/utils.py:112-136 with the same ValueError messages (callers match on them): at least
+    one task; all tasks share batch shape and input dimension with the first one; one output column."""
+    if not meta_data:
         raise ValueError("Empty meta data. Needs at least one source task.")
-    task_id_source_0, data_source_0 = list(meta_data.items())[0]
-    X_shape, Y_shape = data_source_0.X.shape, data_source_0.Y.shape
-    if X_shape[:-2] != Y_shape[:-2]:
-        raise ValueError(f"The X and Y batch sizes of task {task_id_source_0} are not equal.")
-    for task_id, task_data in meta_data.items():
-        if (task_data.X.shape[:-2] != X_shape[:-2] or task_data.Y.shape[:-2] != Y_shape[:-2]
-                or task_data.X.shape[-1] != X_shape[-1]):
-            raise ValueError(f"Dimensions of tasks {task_id_source_0} and {task_id} do not match.")
-        if task_data.Y.shape[-1] != 1:
-            raise ValueError(f"The output dimension of task {task_id} is {task_data.Y.shape[-1]} but must be one")
+    tasks = iter(meta_data.items())
+    first_id, first = next(tasks)
+    batch_x, batch_y, dim = first.X.shape[:-2], first.Y.shape[:-2], first.X.shape[-1]
+    if batch_x != batch_y:
+        raise ValueError(f"The X and Y batch sizes of task {first_id} are not equal.")
+    for tid, data in [(first_id, first), *tasks]:
+        same = data.X.shape[:-2] == batch_x and data.Y.shape[:-2] == batch_y and data.X.shape[-1] == dim
+        if not same:
+            raise ValueError(f"Dimensions of tasks {first_id} and {tid} do not match.")
+        n_out = data.Y.shape[-1]
+        if n_out != 1:
+            raise ValueError(f"The output dimension of task {tid} is {n_out} but must be one")
 
 
 @dataclass(frozen=True)
 class KernelSpec:
-    """What the reference passes as ``covar_module``: ScaleKernel(RBFKernel | MaternKernel(2.5), ARD)."""
+    """Shorthand for ``covar_module``: only the kernel family (RBF | Matern-5/2, ARD), reference priors."""
     kind: int = KIND_RBF
+
+
+def _resolve_modules(likelihood, covar_module, D: int, default_kernel):
+    """What the reference accepts as ``likelihood`` / ``covar_module`` (gpytorch modules, scamlgp/model.py:140-141,
+    223-224) -> (GaussianLikelihood, ScaleKernel) holders of this package.  Also accepted: a HyperSpec as
+    ``likelihood`` (all three parameter groups at once) and a KernelSpec as ``covar_module`` (family only)."""
+    kind = covar_module.kind if isinstance(covar_module, (KernelSpec, hyper.ScaleKernel)) else KIND_RBF
+    if isinstance(likelihood, hyper.HyperSpec):
+        return hyper.modules_from_spec(likelihood, kind, D)
+    if likelihood is not None and not isinstance(likelihood, hyper.GaussianLikelihood):
+        raise TypeError(f"likelihood must be a GaussianLikelihood (or a HyperSpec), got {type(likelihood).__name__}")
+    if covar_module is not None and not isinstance(covar_module, (KernelSpec, hyper.ScaleKernel)):
+        raise TypeError(f"covar_module must be a ScaleKernel (or a KernelSpec), got {type(covar_module).__name__}")
+    lik = likelihood if likelihood is not None else hyper.get_default_likelihood()
+    if isinstance(covar_module, hyper.ScaleKernel):
+        cov = covar_module
+        if cov.base_kernel.ard_num_dims != D:
+            raise ValueError(f"covar_module has ard_num_dims={cov.base_kernel.ard_num_dims} but the inputs have {D} dimensions")
+    else:
+        cov = default_kernel(hyper.MaternKernel if kind == KIND_MATERN52 else hyper.RBFKernel, D)
+    return lik, cov
 
 
 def standardize_fit(Y: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -142,6 +168,8 @@ class SourceGPStack:
         self.n_float = torch.tensor(ns, dtype=torch.float64, device=self.device)
         self.raw = self.spec.to_raw(self.spec.init_theta(self.D, device=self.device)).repeat(T, 1)
         self._fit = None
+        self._rep_cache = {}
+        self.shard: Optional[sdist.TaskShard] = None   # set by meta_fit_scamlgp(shard=True): this stack = tasks [lo, hi) of T_global
 
     # -- hyper-parameters -----------------------------------------------------------------
     @property
@@ -171,23 +199,42 @@ class SourceGPStack:
     def fit(self) -> dict:
         return self._fit if self._fit is not None else self.refresh()
 
+    def _replicated(self, reps: int):
+        """The data of ``reps`` hyper-parameter sets per task, built once per ``reps`` (not per evaluation)."""
+        c = self._rep_cache.get(reps)
+        if c is None:
+            c = dict(X=self.X.repeat(reps, 1, 1) if reps > 1 else self.X, y=self.y.repeat(reps, 1) if reps > 1 else self.y,
+                     npts=None if self.n_points is None else self.n_points.repeat(reps), nflt=self.n_float.repeat(reps), out=None)
+            self._rep_cache = {reps: c}   # one entry: the buffers of another batch size are released
+        return c
+
     def objective(self, raw: torch.Tensor, reps: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
         """Negative training objective and its gradient w.r.t. the raw parameters for ``reps``
         hyper-parameter sets per task: raw (reps * T, D+2), problem b belongs to task b % T.
         objective = -(mll + sum log p(theta) / n)   (gpytorch ExactMarginalLogLikelihood with priors,
-        A5 of SURVEY.md).  One fused-fit launch + one gradient launch for everything."""
-        X = self.X.repeat(reps, 1, 1) if reps > 1 else self.X
-        y = self.y.repeat(reps, 1) if reps > 1 else self.y
-        npts = None if self.n_points is None else self.n_points.repeat(reps)
-        nflt = self.n_float.repeat(reps)
-        theta = self.spec.to_theta(raw)
-        fit = ops.gp_fit_fused(X, y, theta, self.kind, n_points=npts, want_linv=True, zero_upper=False, retry=True)
-        g_theta = ops.mll_backward(X, theta, self.kind, fit["L"], fit["Linv_diag"], fit["alpha"], n_points=npts)
-        f = -(fit["mll"] + self.spec.log_prior(theta) / nflt)
-        g = -(g_theta + self.spec.dlog_prior(theta) / nflt.unsqueeze(-1)) * self.spec.dtheta_draw(raw)
-        bad = fit["info"] > 0
-        f = torch.where(bad, torch.full_like(f, float("nan")), f)
+        A5 of SURVEY.md).  The marginal likelihood is the differentiable op ``ops.FusedMLL`` (one fused-fit
+        launch forward, the analytic gradient kernels backward); constraint transform and priors are torch
+        ops, and torch.autograd chains them -- "autograd stays in PyTorch" (scamlgp/utils.py:175, 190)."""
+        c = self._replicated(reps)
+        raw_ = raw.detach().requires_grad_(True)
+        theta = self.spec.to_theta(raw_)
+        mll = ops.fused_mll(c["X"], c["y"], theta, self.kind, c["npts"], c["out"])
+        if self.N <= ops.fit_max_n():
+            c["out"] = ops.FusedMLL.last   # reuse the factor buffers: backward always runs before the next forward here
+        f = -(mll + self.spec.log_prior(theta) / c["nflt"])
+        bad = ops.FusedMLL.last["info"] > 0
+        (g,) = torch.autograd.grad(torch.where(bad, torch.zeros_like(f), f).sum(), raw_)
+        f = torch.where(bad, torch.full_like(f, float("nan")), f.detach())
         return f, g
+
+    def summed_mll_and_grad(self, theta_shared: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """sum_t MLL_t and sum_t dMLL_t/dtheta at ONE hyper-parameter vector shared by all tasks -- of this stack and,
+        when the stack is a shard, of every rank's: local sums, then one fused all-reduce [sum MLL || sum grad]
+        (BASELINE configs[3]: "RCCL all-reduce of the MLL hyper-gradient")."""
+        th = theta_shared.to(self.device, torch.float64).reshape(1, -1).expand(self.T, -1).contiguous().requires_grad_(True)
+        mll = ops.fused_mll(self.X, self.y, th, self.kind, self.n_points)
+        (g,) = torch.autograd.grad(mll.sum(), th)
+        return sdist.reduce_mll_and_grad(mll.detach(), g, self.shard)
 
     # -- posteriors -----------------------------------------------------------------------
     def posterior(self, xq: torch.Tensor, cov_first: int = 0, want_var: bool = True) -> dict:
@@ -242,19 +289,41 @@ def _stack_of(source_gps: Sequence[SourceGP]) -> Tuple[SourceGPStack, List[int]]
 # ---------------------------------------------------------------------------------------
 # reference API
 # ---------------------------------------------------------------------------------------
+def _canonical_order(X: torch.Tensor, Y: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A task's observations in lexicographic order of (x_0, ..., x_{d-1}, y).  The reference sorts the meta
+    evaluations before it builds the datasets (scamlgp/utils.py:72-109 ``sort_evaluations``) "to ensure that
+    optimization runs are deterministic regardless of the order of input meta evaluations" -- the property its
+    ``is_deterministic_with_shuffled_meta_data`` pins (scamlgp/testing.py:38-99); sorting here gives the kernels
+    bit-identical stacks for shuffled inputs."""
+    import numpy as np
+
+    Xn = torch.as_tensor(X, dtype=torch.float64).reshape(-1, X.shape[-1]).cpu().numpy()
+    Yn = torch.as_tensor(Y, dtype=torch.float64).reshape(-1, 1).cpu().numpy()
+    order = np.lexsort(tuple(np.concatenate([Xn, Yn], 1).T[::-1]))
+    return torch.from_numpy(Xn[order]), torch.from_numpy(Yn[order])
+
+
 def meta_fit_scamlgp(
     meta_data: Dict[Hashable, SupervisedDataset],
-    likelihood: Optional[hyper.HyperSpec] = None,
-    covar_module: Optional[KernelSpec] = None,
+    likelihood: Optional[hyper.GaussianLikelihood] = None,
+    covar_module: Optional[hyper.ScaleKernel] = None,
     num_restarts_log_likelihood: int = 5,
     seed: Optional[int] = None,
     device: Optional[torch.device] = None,
+    shard: bool = False,
+    group=None,
 ) -> Dict[Hashable, SourceGP]:
     """Train the source GPs on the given meta-data (scamlgp/model.py:138-189).
 
-    ``likelihood`` may carry a full HyperSpec (constraints / priors / inits) to override the
-    reference defaults, ``covar_module`` a KernelSpec choosing RBF (default, as in the reference)
-    or Matern-5/2.  All tasks and all restarts are optimised together on the GPU."""
+    ``shard=True`` under an initialised torch.distributed group (one process per GPU): every rank is handed the SAME
+    ``meta_data`` and keeps, fits and returns only its contiguous shard of the tasks (``dist.shard_range``); the
+    tasks are independent, so the fit needs no collective.  A ScaMLGP built on such a dict all-reduces the one
+    coupling of the path -- the weighted sums over tasks (scamlgp/model.py:129-134) -- across the ranks.
+
+    ``likelihood`` / ``covar_module`` are templates, as in the reference (which deep-copies them per task): their
+    constraints, priors and current values become every task's starting point.  Defaults: the reference's
+    Gaussian likelihood and ScaleKernel(RBFKernel) with SingleTaskGP's priors.  All tasks and all restarts are
+    optimised together on the GPU."""
     from .utils import optimize_marginal_likelihood
 
     if seed is not None:
@@ -263,19 +332,26 @@ def meta_fit_scamlgp(
     first = list(meta_data.values())[0]
     if first.X.dim() != 2:
         raise ValueError("batched (batch_shape x n x d) meta-data is not supported by the stacked GPU path")
-    kind = (covar_module or KernelSpec()).kind
-    stack = SourceGPStack(list(meta_data.keys()), [d.X() for d in meta_data.values()], [d.Y() for d in meta_data.values()],
-                          kind=kind, spec=likelihood, device=device)
+    lik, cov = _resolve_modules(likelihood, covar_module, int(first.X.shape[-1]), hyper.get_kernel_source_gp)
+    task_ids, data = list(meta_data.keys()), list(meta_data.values())
+    ts = None
+    if shard:
+        ts = sdist.TaskShard(len(task_ids), group)
+        if ts.hi == ts.lo:
+            raise ValueError(f"rank {ts.rank} of {ts.world} would hold no task: shard fewer ranks than tasks")
+        task_ids, data = task_ids[ts.local], data[ts.local]
+    Xs, Ys = zip(*[_canonical_order(d.X(), d.Y()) for d in data])
+    stack = SourceGPStack(task_ids, Xs, Ys, kind=cov.kind, spec=hyper.spec_from_modules(lik, cov), device=device)
+    stack.shard = ts if ts is not None and ts.world > 1 else None
     optimize_marginal_likelihood(stack, num_restarts=num_restarts_log_likelihood)
     return {tid: SourceGP(stack, i) for i, tid in enumerate(stack.task_ids)}
 
 
 def significant_weights_mask(weights: torch.Tensor, std_Y_vals: torch.Tensor, threshold: float) -> torch.Tensor:
-    """scamlgp/model.py:192-215: w_i sigma_i n_w / sum_j w_j sigma_j >= threshold."""
-    num_weights = len(weights)
-    w_times_sigma = weights * std_Y_vals
-    norm_weights = w_times_sigma * num_weights / w_times_sigma.sum()
-    return norm_weights >= threshold
+    """Pruning criterion of scamlgp/model.py:192-215: task i is kept when its share of the scaled weights,
+    w_i sigma_i / mean_j(w_j sigma_j), reaches ``threshold``."""
+    scaled = weights * std_Y_vals
+    return scaled * scaled.numel() / scaled.sum() >= threshold
 
 
 def _compute_target_prior(x: torch.Tensor, source_gps: List[SourceGP], weights: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -309,12 +385,69 @@ def _kernel_torch(x1: torch.Tensor, x2: torch.Tensor, theta: torch.Tensor, kind:
     return theta[D] * k
 
 
+def psd_safe_cholesky(A: torch.Tensor, max_tries: int = 3) -> torch.Tensor:
+    """linear_operator's psd_safe_cholesky in torch, for the target GP's n x n matrix (n <= ~80; the reference
+    reaches it through scamlgp/utils.py:171-177 for the target fit as for the source fits): try as is; on failure
+    add 1e-8, 1e-7, 1e-6 to the diagonal in turn (each try replaces the previous jitter); then NotPSDError.  NaN in
+    A raises at once.  Differentiable (the jitter is a constant shift)."""
+    if bool(torch.isnan(A).any()):
+        raise ops.NotPSDError(f"cholesky_cpu: {int(torch.isnan(A).sum())} of {A.numel()} elements of the matrix are NaN.")
+    L, info = torch.linalg.cholesky_ex(A)
+    if not bool(info.any()):
+        return L
+    eye = torch.eye(A.shape[-1], dtype=A.dtype, device=A.device)
+    for i in range(max_tries):
+        jitter = 1e-8 * 10 ** i
+        warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", RuntimeWarning)
+        L, info = torch.linalg.cholesky_ex(A + jitter * eye)
+        if not bool(info.any()):
+            return L
+    raise ops.NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
+
+
+class _LazyMVN:
+    """``posterior(X).mvn``: mean (M,), variance (M,) at once; the joint (M, M) covariance only when asked for
+    (an acquisition function over 1 000 candidates never needs it)."""
+
+    def __init__(self, mean: torch.Tensor, variance: torch.Tensor, cov_fn):
+        self.mean, self.variance, self._cov_fn, self._cov = mean, variance, cov_fn, None
+
+    @property
+    def covariance_matrix(self) -> torch.Tensor:
+        if self._cov is None:
+            self._cov = self._cov_fn()
+        return self._cov
+
+    lazy_covariance_matrix = covariance_matrix
+
+    @property
+    def stddev(self) -> torch.Tensor:
+        return self.variance.clamp_min(0.0).sqrt()
+
+
+class TargetPosterior:
+    """What botorch's ``model.posterior(X)`` returns, reduced to what its callers read: ``.mean`` / ``.variance``
+    as (M, 1) columns, ``.mvn.mean`` (M,), ``.mvn.variance`` (M,), ``.mvn.covariance_matrix`` (M, M)."""
+
+    def __init__(self, mean: torch.Tensor, variance: torch.Tensor, cov_fn):
+        self.mvn = _LazyMVN(mean, variance, cov_fn)
+
+    mean = property(lambda self: self.mvn.mean.unsqueeze(-1))
+    variance = property(lambda self: self.mvn.variance.unsqueeze(-1))
+
+
 class ScaMLGP:
     """Scalable meta-learning GP (scamlgp/model.py:218-384): target prior
-    N(sum_i w_i mu_i, sum_i w_i^2 Sigma_i + k_t) over the posteriors of the source stack."""
+    N(sum_i w_i mu_i, sum_i w_i^2 Sigma_i + k_t) over the posteriors of the source stack.
+
+    Same constructor arguments and attributes as the reference class: ``likelihood`` / ``covar_module`` are the
+    parameter-carrying modules (``hyper.GaussianLikelihood``, ``hyper.ScaleKernel``; the fitted ones of a previous
+    model may be passed back in, scamlgp/optimizer.py:176-183), ``train_inputs``, ``train_targets``, ``weights``,
+    ``source_gps``, ``source_means``, ``source_covs``, ``forward``, ``posterior``, ``train`` / ``eval``,
+    ``state_dict`` / ``load_state_dict``."""
 
     def __init__(self, train_X: torch.Tensor, train_Y: torch.Tensor, source_gps: Dict[Hashable, SourceGP],
-                 likelihood: Optional[hyper.HyperSpec] = None, covar_module: Optional[KernelSpec] = None,
+                 likelihood: Optional[hyper.GaussianLikelihood] = None, covar_module: Optional[hyper.ScaleKernel] = None,
                  weight_pruning_threshold: float = 1e-3) -> None:
         self._weight_pruning_threshold = weight_pruning_threshold
         self.source_gps = source_gps
@@ -324,21 +457,30 @@ class ScaMLGP:
         self.device = dev
         self.train_X = torch.as_tensor(train_X, dtype=torch.float64).reshape(-1, self._stack.D).to(dev)
         self.train_Y = torch.as_tensor(train_Y, dtype=torch.float64).reshape(-1, 1).to(dev)
-        self.n, self.T = self.train_X.shape[0], len(gps)
-        self.kind = (covar_module or KernelSpec()).kind
-        self.spec = likelihood or hyper.target_gp_spec()
+        self._shard = self._stack.shard
+        if self._shard is not None and len(gps) != self._stack.T:
+            raise ValueError("a sharded source stack must be passed whole (every rank its full shard)")
+        self.n, self.T = self.train_X.shape[0], (self._shard.n_tasks if self._shard is not None else len(gps))
+        lik, cov = _resolve_modules(likelihood, covar_module, self._stack.D, hyper.get_default_kernel)
+        self.likelihood, self.covar_module = lik.to(dev), cov.to(dev)
+        self.kind = cov.kind
+        self.spec = hyper.spec_from_modules(lik, cov)
         # standardise w.r.t. ALL meta + target observations (scamlgp/model.py:264-276)
-        Y_all = torch.cat([self._stack.raw_targets(), self.train_Y], dim=-2)
         self.has_transform = self.train_Y.numel() > 0
-        m, s = standardize_fit(Y_all)
-        self.m_all, self.s_all = (m.squeeze(), s.squeeze()) if self.has_transform else (Y_all.new_zeros(()), Y_all.new_ones(()))
+        if self._shard is None:
+            m, s = standardize_fit(torch.cat([self._stack.raw_targets(), self.train_Y], dim=-2))
+        else:   # the same statistics from all-reduced sums: no rank ever holds the other shards' observations
+            m, s = sdist.standardize_fit_sharded(self._stack.raw_targets(), self.train_Y, self._shard)
+        self.m_all, self.s_all = (m.squeeze(), s.squeeze()) if self.has_transform else (self.train_Y.new_zeros(()), self.train_Y.new_ones(()))
+        self.outcome_transform = _OutcomeTransform(self.m_all, self.s_all) if self.has_transform else None
+        self.train_inputs = (self.train_X,)
         self.train_targets = ((self.train_Y - self.m_all) / self.s_all).squeeze(-1)
         # cached source posteriors at the target inputs, all tasks, no pruning (scamlgp/model.py:279-289)
         if self.n > 0:
             p = self._stack.posterior(self.train_X, cov_first=self.n)
-            self.source_means = p["mean"][self._idx].transpose(0, 1).contiguous()          # (n, T)
-            self.source_covs = p["cov"][self._idx].permute(1, 2, 0).contiguous()           # (n, n, T)
-        self.raw_theta = self.spec.to_raw(self.spec.init_theta(self._stack.D, device=dev))
+            # (sharded: every rank contributes its tasks' columns, one all-reduce each -- n <= ~80, tiny)
+            self.source_means = sdist.gather_task_axis(p["mean"][self._idx].transpose(0, 1).contiguous(), self._shard)   # (n, T)
+            self.source_covs = sdist.gather_task_axis(p["cov"][self._idx].permute(1, 2, 0).contiguous(), self._shard)    # (n, n, T)
         self.raw_weights = torch.full((self.T,), 1.0 / self.T, dtype=torch.float64, device=dev)
         self.weights_prior = hyper.GammaPrior(1.0, 1.0)
         self.weights_lower_bound = 1e-10   # GreaterThan(1e-10, transform=None): a box bound for the optimiser
@@ -352,6 +494,20 @@ class ScaMLGP:
     @weights.setter
     def weights(self, value) -> None:
         self.raw_weights = torch.as_tensor(value, dtype=torch.float64).to(self.device)
+
+    @property
+    def raw_theta(self) -> torch.Tensor:
+        """[raw lengthscales (D), raw outputscale, raw noise]: the modules' parameters as one vector."""
+        cov, lik = self.covar_module, self.likelihood
+        return torch.cat([cov.base_kernel.raw_lengthscale.reshape(-1), cov.raw_outputscale.reshape(1), lik.raw_noise.reshape(1)])
+
+    @raw_theta.setter
+    def raw_theta(self, value: torch.Tensor) -> None:
+        v = torch.as_tensor(value, dtype=torch.float64).to(self.device).detach()
+        D = self._stack.D
+        self.covar_module.base_kernel._p.raw = v[:D].clone()
+        self.covar_module._p.raw = v[D].clone()
+        self.likelihood._p.raw = v[D + 1].clone()
 
     @property
     def theta(self) -> torch.Tensor:
@@ -373,7 +529,34 @@ class ScaMLGP:
 
     # -- model ------------------------------------------------------------------------------
     def _std_source_stds(self) -> torch.Tensor:
-        return self._stack.y_std[self._idx]
+        if getattr(self, "_stds_all", None) is None:
+            self._stds_all = sdist.gather_task_axis(self._stack.y_std[self._idx], self._shard)
+        return self._stds_all
+
+    def _active_tasks(self):
+        """Pruned weights as vectors over this rank's stack: w_full (T_stack,), active mask (bool)
+        (scamlgp/model.py:365-372; the mask is decided on ALL T weights, each rank then takes its slice)."""
+        w = self.weights
+        mask = significant_weights_mask(w, self._std_source_stds(), self._weight_pruning_threshold)
+        if self._shard is not None:
+            w, mask = w[self._shard.local], mask[self._shard.local]
+        idx = torch.as_tensor(self._idx, device=self.device)
+        w_full = torch.zeros(self._stack.T, dtype=torch.float64, device=self.device)
+        w_full[idx] = w
+        active = torch.zeros(self._stack.T, dtype=torch.bool, device=self.device)
+        active[idx[mask]] = True
+        return w_full, active
+
+    def _source_prior(self, x: torch.Tensor, cov_first: int):
+        """sum_i w_i mu_i(x) (M,), sum_i w_i^2 Sigma_i (cov_first, M), sum_i w_i^2 var_i (M,) over the significant tasks
+        of ALL ranks, in original units: one batched posterior launch over this rank's stack, the weighted task sums,
+        and -- sharded -- ONE all-reduce of the fused buffer [mu_s || Sigma_s || var_s]."""
+        w_full, active = self._active_tasks()
+        p = self._stack.posterior(x, cov_first=cov_first)
+        mu_s, cov_s = ops.weighted_prior_reduce(p["mean"], p["cov"], w_full, active)
+        var_s = ops.weighted_task_sum(p["var"], w_full, 2, active)
+        mu_s, cov_s, var_s = sdist.fused_allreduce([mu_s, cov_s, var_s], self._shard)
+        return mu_s, cov_s, var_s
 
     def forward(self, x: torch.Tensor) -> _MVN:
         """scamlgp/model.py:359-384.  Training: cached source terms at train_X; eval: pruned weights and a
@@ -384,15 +567,15 @@ class ScaMLGP:
             mean = self.source_means @ w
             cov = self.source_covs @ w ** 2
         else:
-            mask = significant_weights_mask(w, self._std_source_stds(), self._weight_pruning_threshold)
-            gps = [g for g, keep in zip(self.source_gps.values(), mask.tolist()) if keep]
-            mean, cov = _compute_target_prior(x, gps, w[mask])
-            mean = mean.squeeze(-1)
+            # = _compute_target_prior over the significant models (scamlgp/model.py:365-375), as stack-wide sums
+            mean, cov, _ = self._source_prior(x, x.shape[0])
         if self.has_transform:
             mean = (mean - self.m_all) / self.s_all
             cov = cov / self.s_all ** 2
         cov = cov + _kernel_torch(x, x, self.theta, self.kind)
         return _MVN(mean, cov)
+
+    __call__ = forward
 
     def mll(self, raw_theta: Optional[torch.Tensor] = None, raw_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Training objective (A9): [log N(y~ | mean, cov + sigma^2 I) + log priors] / n, differentiable in torch."""
@@ -402,39 +585,41 @@ class ScaMLGP:
         mean = (self.source_means @ w - self.m_all) / self.s_all
         cov = (self.source_covs @ w ** 2) / self.s_all ** 2 + _kernel_torch(self.train_X, self.train_X, theta, self.kind)
         cov = cov + theta[-1] * torch.eye(self.n, dtype=torch.float64, device=self.device)
-        Lc = torch.linalg.cholesky(cov)
+        Lc = psd_safe_cholesky(cov)
         v = torch.linalg.solve_triangular(Lc, (self.train_targets - mean).unsqueeze(-1), upper=False)
         val = -0.5 * ((v * v).sum() + 2.0 * torch.log(torch.diagonal(Lc)).sum() + self.n * _LOG_2PI)
         val = val + self.spec.log_prior(theta) + self.weights_prior.log_prob(w).sum()
         return val / self.n
 
-    def posterior(self, X: torch.Tensor, observation_noise: bool = False):
-        """Target posterior at X (M, D) in original units (A10): mean (M,), variance (M,).  The source
-        prior is evaluated ONCE at cat(train_X, X) — train block, cross block and query diagonal — instead
-        of once per query as the reference does."""
-        Xq = torch.as_tensor(X, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device)
-        M, n = Xq.shape[0], self.n
-        w = self.weights
-        mask = significant_weights_mask(w, self._std_source_stds(), self._weight_pruning_threshold)
-        w_full = torch.zeros(self._stack.T, dtype=torch.float64, device=self.device)
-        w_full[self._idx] = w
-        active = torch.zeros(self._stack.T, dtype=torch.bool, device=self.device)
-        active[torch.as_tensor(self._idx, device=self.device)[mask]] = True
+    def _joint(self, Xq: torch.Tensor, full: bool):
+        """Standardised joint prior over cat(train_X, Xq) (A8, A10) from ONE source-posterior launch: mean (n + M,),
+        the n x (n + M) covariance block (or the whole (n + M)^2 one with ``full``) and the query diagonal."""
+        n, M = self.n, Xq.shape[0]
         xall = torch.cat([self.train_X, Xq], 0)
-        p = self._stack.posterior(xall, cov_first=n)
-        mu_s = ops.weighted_task_sum(p["mean"], w_full, 1, active)
-        var_s = ops.weighted_task_sum(p["var"], w_full, 2, active)
+        first = n + M if full else n
+        mu_s, cov_s, var_s = self._source_prior(xall, first)
         theta = self.theta
         mean = (mu_s - self.m_all) / self.s_all
         var_q = var_s[n:] / self.s_all ** 2 + theta[-2]
+        cov = None
+        if first > 0:
+            cov = cov_s / self.s_all ** 2 + _kernel_torch(xall[:first], xall, theta, self.kind)
+        return mean, cov, var_q, theta
+
+    def posterior(self, X: torch.Tensor, observation_noise: bool = False) -> TargetPosterior:
+        """Target posterior at X (M, D) in original units (A10).  The source prior is evaluated ONCE at
+        cat(train_X, X) -- train block, cross block and query diagonal -- instead of once per query as the
+        reference does.  ``.mvn.covariance_matrix`` (the joint (M, M) covariance) costs a second
+        launch with the full query block and is only computed when read."""
+        Xq = torch.as_tensor(X, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device)
+        n = self.n
+        mean, cov, var_q, theta = self._joint(Xq, full=False)
         if n == 0:
             mu, var = mean, var_q
         else:
-            cov_s = ops.weighted_task_sum(p["cov"], w_full, 2, active) / self.s_all ** 2
-            Knn = cov_s[:, :n] + _kernel_torch(self.train_X, self.train_X, theta, self.kind)
-            Knn = Knn + theta[-1] * torch.eye(n, dtype=torch.float64, device=self.device)
-            Knq = cov_s[:, n:] + _kernel_torch(self.train_X, Xq, theta, self.kind)
-            Lc = torch.linalg.cholesky(Knn)
+            Knn = cov[:, :n] + theta[-1] * torch.eye(n, dtype=torch.float64, device=self.device)
+            Knq = cov[:, n:]
+            Lc = psd_safe_cholesky(Knn)
             resid = (self.train_targets - mean[:n]).unsqueeze(-1)
             a = torch.cholesky_solve(resid, Lc).squeeze(-1)
             mu = mean[n:] + Knq.transpose(0, 1) @ a
@@ -442,10 +627,16 @@ class ScaMLGP:
             var = var_q - (Vq * Vq).sum(0)
         if observation_noise:
             var = var + theta[-1]
-        return TargetPosterior(self.m_all + self.s_all * mu, self.s_all ** 2 * var)
 
+        def full_cov() -> torch.Tensor:
+            _, cj, _, th = self._joint(Xq, full=True)
+            S = cj[n:, n:]
+            if n > 0:
+                Lc2 = psd_safe_cholesky(cj[:n, :n] + th[-1] * torch.eye(n, dtype=torch.float64, device=self.device))
+                V2 = torch.linalg.solve_triangular(Lc2, cj[:n, n:], upper=False)
+                S = S - V2.transpose(0, 1) @ V2
+            if observation_noise:
+                S = S + th[-1] * torch.eye(S.shape[0], dtype=torch.float64, device=self.device)
+            return self.s_all ** 2 * S
 
-@dataclass
-class TargetPosterior:
-    mean: torch.Tensor      # (M,)
-    variance: torch.Tensor  # (M,)
+        return TargetPosterior(self.m_all + self.s_all * mu, self.s_all ** 2 * var, full_cov)

@@ -38,6 +38,11 @@ def _stream_handle() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def fit_max_n() -> int:
+    """Largest N the single-launch fused fit takes (scaml_fit_max_n)."""
+    return int(_lib.lib.scaml_fit_max_n())
+
+
 def gp_fit_fused(
     X: torch.Tensor,
     y: torch.Tensor,
@@ -79,6 +84,10 @@ def gp_fit_fused(
         if out is not None:
             L, alpha, quad, logdet, mll, info, jit_used = (out[k] for k in ("L", "alpha", "quad", "logdet", "mll", "info", "jitter"))
             linv = out.get("Linv_diag")
+            if want_linv and linv is None:
+                raise ValueError("out= has no Linv_diag buffer but want_linv=True")
+            if not want_linv:
+                linv = None
             if (L is None) == store_L or (alpha is None) == want_alpha or quad.shape != (T,) or (store_L and L.shape != (T, N, N)):
                 raise ValueError("out= does not match this call's shapes/flags")
         else:
@@ -389,6 +398,15 @@ def weighted_prior_reduce(mu: Optional[torch.Tensor], cov: Optional[torch.Tensor
     return mu_s, cov_s
 
 
+def mll_backward_workspace(T: int, N: int, D: int, device) -> Dict[str, torch.Tensor]:
+    """Reusable buffers of ``mll_backward`` for a (T, N, D) stack: the explicit inverse factors (T N^2 doubles) and
+    the per-tile partial sums.  An optimiser loop allocates them once (scaml_mll_backward_workspace_doubles)."""
+    nb = (N + 15) // 16
+    nt = nb * (nb + 1) // 2
+    return dict(work=torch.empty((T * N * N,), dtype=torch.float64, device=device),
+                partials=torch.empty((T, nt, D + 2), dtype=torch.float64, device=device), shape=(T, N, D))
+
+
 def mll_backward(
     X: torch.Tensor,
     theta: torch.Tensor,
@@ -397,10 +415,12 @@ def mll_backward(
     Linv_diag: torch.Tensor,
     alpha: torch.Tensor,
     n_points: Optional[torch.Tensor] = None,
+    workspace: Optional[Dict[str, torch.Tensor]] = None,
 ) -> torch.Tensor:
     """d mll[t] / d theta[t] (T, D+2) for the constrained hyper-parameters, from the outputs of
     ``gp_fit_fused(..., want_linv=True)``.  Launches scaml_mll_backward_f64; the final sum over the
-    per-tile partials and the 1 / (2 n_t) scaling are two tiny torch ops."""
+    per-tile partials and the 1 / (2 n_t) scaling are two tiny torch ops.  ``workspace`` (from
+    ``mll_backward_workspace``) is reused across calls instead of allocating T N^2 doubles each time."""
     T, N, D = X.shape
     X = _check(X, "X")
     theta = _check(theta, "theta", (T, D + 2))
@@ -409,17 +429,61 @@ def mll_backward(
     alpha = _check(alpha, "alpha", (T, N))
     if n_points is not None:
         n_points = _check(n_points, "n_points", (T,), torch.int32)
-    nb = (N + 15) // 16
-    nt = nb * (nb + 1) // 2
     dev = X.device
+    if workspace is None:
+        workspace = mll_backward_workspace(T, N, D, dev)
+    elif workspace["shape"] != (T, N, D) or workspace["work"].device != dev:
+        raise ValueError("workspace does not match this call's (T, N, D) / device")
+    work, partials = workspace["work"], workspace["partials"]
     with torch.cuda.device(dev):
-        work = torch.empty((T * N * N,), dtype=torch.float64, device=dev)
-        partials = torch.empty((T, nt, D + 2), dtype=torch.float64, device=dev)
         rc = _lib.lib.scaml_mll_backward_f64(_ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(n_points),
                                              T, N, D, int(kind), _ptr(work), _ptr(partials), _stream_handle())
     _lib.check_rc(rc, "scaml_mll_backward_f64")
     n = n_points.to(torch.float64) if n_points is not None else torch.full((T,), float(N), dtype=torch.float64, device=dev)
     return partials.sum(1) / (2.0 * n.clamp_min(1.0)).unsqueeze(-1)
+
+
+class FusedMLL(torch.autograd.Function):
+    """mll (T,) = FusedMLL.apply(X, y, theta, kind, n_points): the marginal log-likelihood of every task of the
+    stack as a differentiable torch op.  forward = one launch of scaml_gp_fit_fused_f64 (K, jittered Cholesky,
+    alpha, MLL), backward = scaml_mll_backward_f64 (analytic d mll / d theta; no gradient flows to X or y).
+    Replaces the autograd pass through kernel -> Cholesky -> solves that botorch's fit_gpytorch_mll runs per
+    L-BFGS-B iteration (scamlgp/utils.py:175, 190).  Tasks whose factorisation fails even with jitter give
+    mll = NaN and a zero gradient; ``FusedMLL.last`` keeps the last forward's outputs (info, jitter, L, alpha)."""
+
+    last: Optional[Dict[str, torch.Tensor]] = None
+    workspace: Optional[Dict[str, torch.Tensor]] = None
+
+    @staticmethod
+    def forward(ctx, X, y, theta, kind, n_points=None, out=None):
+        # (N > scaml_fit_max_n() goes through the two-block composite, which allocates its own outputs)
+        if out is not None and X.shape[1] > _lib.lib.scaml_fit_max_n():
+            out = None
+        fit = gp_fit_fused(X.detach(), y.detach(), theta.detach(), kind, n_points=n_points, want_linv=True, zero_upper=False,
+                           out=out)
+        ctx.kind, ctx.n_points = int(kind), n_points
+        ctx.save_for_backward(X.detach(), theta.detach(), fit["L"], fit["Linv_diag"], fit["alpha"], fit["info"])
+        FusedMLL.last = fit
+        return fit["mll"].clone()
+
+    @staticmethod
+    def backward(ctx, grad_mll):
+        X, theta, L, Linv_diag, alpha, info = ctx.saved_tensors
+        ws = FusedMLL.workspace
+        if ws is not None and (ws["shape"] != tuple(X.shape) or ws["work"].device != X.device):
+            ws = None
+        if ws is None:
+            ws = FusedMLL.workspace = mll_backward_workspace(*X.shape, X.device)
+        g = mll_backward(X, theta, ctx.kind, L, Linv_diag, alpha, n_points=ctx.n_points, workspace=ws)
+        g = torch.where((info > 0).unsqueeze(-1), torch.zeros_like(g), g)
+        return None, None, g * grad_mll.unsqueeze(-1), None, None, None
+
+
+def fused_mll(X: torch.Tensor, y: torch.Tensor, theta: torch.Tensor, kind: int,
+              n_points: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """Functional form of ``FusedMLL``.  ``out`` (the dict ``FusedMLL.last`` of an earlier call with the same shapes)
+    lets an optimiser loop reuse the factor buffers: the caller then runs backward before the next forward."""
+    return FusedMLL.apply(X, y, theta, kind, n_points, out)
 
 
 def raise_if_not_psd(info: torch.Tensor) -> None:

@@ -12,6 +12,7 @@ Plain Python: nothing here touches the GPU path.
 from __future__ import annotations
 
 import hashlib
+import itertools
 import json
 import os
 import time
@@ -21,15 +22,15 @@ from typing import Any, Dict, Iterable, List, Optional, Sequence
 
 def compute_regrets(objective_name: str, optimum: float, objective_values: Sequence[Dict[str, float]],
                     greater_is_better: bool = False) -> List[float]:
-    """Regret after every evaluation: loss_t - loss*, then its running minimum."""
+    """Simple regret curve (what scamlgp/benchmarking/plotting.py:21-53 plots): the instantaneous regret
+    sign * (value_t - optimum) of every evaluation, then its cumulative minimum.  A regret below -1e-6 (the tabulated
+    optimum of some benchmarks is itself an estimate) is reported with a warning, as the reference does."""
     sign = -1.0 if greater_is_better else 1.0
-    regrets: List[float] = []
-    for ovs in objective_values:
-        regret = sign * ovs[objective_name] - sign * optimum
-        if regret < -1e-6:
-            warnings.warn(f"A negative regret was detected. The regret value was {regret}.", Warning)
-        regrets.append(regret if not regrets else min(regret, regrets[-1]))
-    return regrets
+    inst = [sign * ovs[objective_name] - sign * optimum for ovs in objective_values]
+    for r in inst:
+        if r < -1e-6:
+            warnings.warn(f"A negative regret was detected. The regret value was {r}.", Warning)
+    return list(itertools.accumulate(inst, min))
 
 
 def study_record(X: Iterable[Sequence[float]], Y_noisy: Iterable[float], Y_noise_free: Optional[Iterable[float]] = None, *,
@@ -57,10 +58,17 @@ def regrets_of_study(study: Dict[str, Any], noise_free: bool = True) -> List[flo
     return compute_regrets(key, study["optimum"], [e["objectives"] for e in study["evaluations"]], obj["greater_is_better"])
 
 
+def config_hash_of(experiment_config: Dict[str, Any], short: bool = False) -> str:
+    """SHA-256 of the JSON text of the parsed experiment configuration, optionally cut to 7 characters
+    (scamlgp/benchmarking/experiment_config_utils.py:95-100: same digest, so result file names line up)."""
+    digest = hashlib.sha256(json.dumps(experiment_config).encode()).hexdigest()
+    return digest[:7] if short else digest
+
+
 def write_study(output_dir: str, experiment_key: str, experiment_config: Dict[str, Any], study: Dict[str, Any],
                 experiment_module: str = "scamlgp_amd") -> str:
     """<output_dir>/<experiment_key>_<seed>_<config hash>.json, one study per file."""
-    config_hash = hashlib.md5(json.dumps(experiment_config, sort_keys=True, default=str).encode()).hexdigest()
+    config_hash = config_hash_of(experiment_config)
     results = dict(experiment_config=experiment_config, experiment_module=experiment_module, experiment_key=experiment_key,
                    timestamp=time.time(), studies=[study])
     os.makedirs(output_dir, exist_ok=True)

@@ -16,6 +16,7 @@ import numpy as np
 import scipy.optimize
 import torch
 
+from . import dist as sdist
 from . import hyper
 from .model import ScaMLGP, SourceGP, SourceGPStack
 
@@ -48,7 +49,10 @@ def _fit_stack(stack: SourceGPStack, num_restarts: int, max_iter: int = 200) -> 
         logger.warning("%d of %d hyper-parameter optimisation attempts failed and were skipped.", n_failed, f.numel())
     stack.raw = res.x.reshape(reps, T, D + 2)[best, torch.arange(T, device=stack.device)].contiguous()
     stack.refresh()
-    stack.last_fit_info = dict(n_iter=res.n_iter, n_eval=res.n_eval, objective=-f.min(0).values)
+    obj = -f.min(0).values
+    # (a sharded stack also reports the objective summed over every rank's tasks: the fit's one collective)
+    total = sdist.fused_allreduce([obj.sum().reshape(1)], stack.shard)[0]
+    stack.last_fit_info = dict(n_iter=res.n_iter, n_eval=res.n_eval, objective=obj, objective_sum=total.squeeze(0))
 
 
 def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200) -> None:
@@ -112,26 +116,28 @@ def optimize_marginal_likelihood(model: Union[SourceGPStack, ScaMLGP, Dict, Sour
 
 # --- acquisition functions (to be MAXIMISED, for minimising the objective) -------------------------
 class UpperConfidenceBound:
-    """botorch UpperConfidenceBound(model, beta=9.0, maximize=False): value = -mu + sqrt(beta * var)."""
+    """botorch UpperConfidenceBound(model, beta=9.0, maximize=False) (scamlgp/utils.py:215-224):
+    value = -mu + sqrt(beta * var) per query point; X (M, D) -> (M,)."""
 
     def __init__(self, model: ScaMLGP, beta: float = 9.0):
         self.model, self.beta = model, beta
 
     def __call__(self, X: torch.Tensor) -> torch.Tensor:
-        p = self.model.posterior(X)
-        return -p.mean + torch.sqrt(self.beta * p.variance.clamp_min(0.0))
+        mvn = self.model.posterior(X).mvn
+        return -mvn.mean + torch.sqrt(self.beta * mvn.variance.clamp_min(0.0))
 
 
 class ExpectedImprovement:
-    """botorch analytic ExpectedImprovement(model, best_f, maximize=False)."""
+    """botorch analytic ExpectedImprovement(model, best_f, maximize=False) (scamlgp/optimizer.py:96-98):
+    sigma = sqrt(max(var, 1e-9)), u = -(mu - best_f) / sigma, EI = sigma (phi(u) + u Phi(u))."""
 
     def __init__(self, model: ScaMLGP, best_f: float):
         self.model, self.best_f = model, best_f
 
     def __call__(self, X: torch.Tensor) -> torch.Tensor:
-        p = self.model.posterior(X)
-        sigma = p.variance.clamp_min(1e-9).sqrt()
-        u = -(p.mean - self.best_f) / sigma
+        mvn = self.model.posterior(X).mvn
+        sigma = mvn.variance.clamp_min(1e-9).sqrt()
+        u = -(mvn.mean - self.best_f) / sigma
         pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
         cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
         return sigma * (pdf + u * cdf)

@@ -1,0 +1,144 @@
+"""BASELINE.json configs[3] and configs[4] at their full sizes on one GPU.
+
+configs[3]: 1024 meta-tasks x 256 points (D = 8, Matern-5/2), task-sharded 8x, all-reduce of the summed MLL /
+            hyper-gradient -- here: the 8 shards of `dist.shard_range(1024, 8, r)` run one after the other on the one
+            GPU; their [sum MLL || sum dMLL/dtheta] buffers must add up to the unsharded launch's, sampled tasks are
+            checked against the oracle, and the per-GPU shard shape (T = 128) is run on its own.
+configs[4]: BO loop on Hartmann-6, source tasks of 512 points, posterior + EI every step -- three steps of the loop; at
+            every step UCB and EI on 32 candidates are compared with the oracle's acquisition values on the oracle's
+            target posterior (rel. 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp_oracle as O
+from scamlgp_amd import dist as sdist
+from scamlgp_amd import model as M, ops, synthetic, utils
+from scamlgp_amd.bo import ScaMLGPBOLoop, optimize_acqf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_1024_tasks_sharded_sums(device):
+    T, N, D, world = 1024, 256, 8, 8
+    kind = O.KIND_MATERN52
+    d = synthetic.smooth_field_task_stack(T, N, D, seed=77)
+    ys, _, _ = synthetic.standardize_rows(d["Y"])
+    rng = np.random.default_rng(7)
+    theta = np.concatenate([0.5 * (1 + 0.4 * (rng.uniform(size=(T, D)) - 0.5)), np.full((T, 1), 1.0), np.full((T, 1), 1e-3)], 1)
+    Xh, yh, thh = torch.from_numpy(d["X"]), torch.from_numpy(ys), torch.from_numpy(theta)
+    X, y, th = Xh.to(device), yh.to(device), thh.to(device)
+    # unsharded: one launch over all 1024 tasks (fit, then gradient)
+    full = ops.gp_fit_fused(X, y, th, kind, want_linv=True, zero_upper=False)
+    assert not bool(full["info"].any())
+    g_full = ops.mll_backward(X, th, kind, full["L"], full["Linv_diag"], full["alpha"])
+    buf_full = torch.cat([full["mll"].sum().reshape(1), g_full.sum(0)])
+    mll_full, alpha_full = full["mll"].clone(), full["alpha"].clone()
+    del full
+    # the 8 shards, each as its rank would run it (T = 128 per launch), reduced as the all-reduce would
+    buf = torch.zeros(D + 3, dtype=torch.float64, device=device)
+    ws = ops.mll_backward_workspace(T // world, N, D, device)
+    for r in range(world):
+        lo, hi = sdist.shard_range(T, world, r)
+        assert hi - lo == 128
+        f = ops.gp_fit_fused(X[lo:hi], y[lo:hi], th[lo:hi], kind, want_linv=True, zero_upper=False)
+        g = ops.mll_backward(X[lo:hi], th[lo:hi], kind, f["L"], f["Linv_diag"], f["alpha"], workspace=ws)
+        s_mll, s_grad = sdist.reduce_mll_and_grad(f["mll"], g)
+        buf += torch.cat([s_mll.reshape(1), s_grad])
+        # a shard's tasks get the same numbers as inside the full launch
+        torch.testing.assert_close(f["mll"], mll_full[lo:hi], rtol=1e-12, atol=0)
+        torch.testing.assert_close(f["alpha"], alpha_full[lo:hi], rtol=1e-9, atol=1e-12)
+        torch.testing.assert_close(g, g_full[lo:hi], rtol=1e-9, atol=1e-13)
+    torch.testing.assert_close(buf, buf_full, rtol=1e-10, atol=1e-12)
+    # three sampled tasks against the oracle (1e-3 on the MLL, 1e-4 on alpha and on the gradient)
+    for t in (0, 517, 1023):
+        ref = O.gp_fit(Xh[t], yh[t], thh[t], kind)
+        np.testing.assert_allclose(float(mll_full[t]), float(ref["mll"]), rtol=1e-3)
+        a = alpha_full[t].cpu()
+        torch.testing.assert_close(a, ref["alpha"], rtol=1e-4, atol=1e-4 * float(ref["alpha"].abs().max()))
+        th_t = thh[t].clone().requires_grad_(True)
+        K = O.kernel_matrix(Xh[t], None, th_t[:D], th_t[D], kind) + th_t[-1] * torch.eye(N, dtype=torch.float64)
+        Lc = torch.linalg.cholesky(K)
+        v = torch.linalg.solve_triangular(Lc, yh[t].unsqueeze(-1), upper=False)
+        val = -0.5 * ((v * v).sum() + 2 * torch.log(torch.diagonal(Lc)).sum() + N * np.log(2 * np.pi)) / N
+        (gref,) = torch.autograd.grad(val, th_t)
+        np.testing.assert_allclose(g_full[t].cpu().numpy(), gref.numpy(), rtol=1e-4, atol=1e-4 * float(gref.abs().max()))
+
+
+def _hartmann6_stack(device, T=4, N=512, max_iter=8):
+    d = synthetic.hartmann6_task_stack(T, N, seed=9, noise_std=0.1)
+    stack = M.SourceGPStack([f"h{t}" for t in range(T)], [torch.from_numpy(d["X"][t]) for t in range(T)],
+                            [torch.from_numpy(d["Y"][t]).unsqueeze(-1) for t in range(T)], kind=O.KIND_MATERN52, device=device)
+    utils._fit_stack(stack, num_restarts=0, max_iter=max_iter)
+    return stack, {tid: M.SourceGP(stack, i) for i, tid in enumerate(stack.task_ids)}
+
+
+def _oracle_target_posterior(model, stack_fits, xq):
+    """The oracle's target posterior at xq for the model's current data / weights / hyper-parameters."""
+    stack = model._stack
+    w = model.weights.cpu()
+    stds = stack.y_std.cpu()
+    mask = O.significant_weights_mask(w, stds, 1e-3)
+    xall = torch.cat([model.train_X.cpu(), xq])
+    mus, covs = [], []
+    for t in range(stack.T):
+        if not bool(mask[t]):
+            continue
+        fit = stack_fits[t]
+        mu, cov = O.source_posterior(xall, stack.X[t].cpu(), stack.theta[t].cpu(), stack.kind, fit["L"], fit["alpha"],
+                                     float(stack.y_mean[t]), float(stack.y_std[t]))
+        mus.append(mu)
+        covs.append(cov)
+    mu_j, cov_j = O.target_prior(torch.stack(mus), torch.stack(covs), w[mask])
+    return O.target_posterior(xq, model.train_X.cpu(), model.train_Y.cpu().squeeze(-1), mu_j, cov_j, model.theta.cpu(), model.kind,
+                              float(model.m_all), float(model.s_all))
+
+
+def test_config4_bo_loop_hartmann6_ei_matches_oracle(device):
+    stack, gps = _hartmann6_stack(device)
+    fits = [O.gp_fit(stack.X[t].cpu(), stack.y[t].cpu(), stack.theta[t].cpu(), stack.kind) for t in range(stack.T)]
+
+    def objective(x):
+        return float(synthetic.hartmann6(np.asarray(x, dtype=np.float64).reshape(1, -1), alpha=np.array([1.01, 1.19, 2.9, 3.3]))[0])
+
+    loop = ScaMLGPBOLoop(gps, dim=6, acquisition="ei", num_restarts_log_likelihood=1, raw_samples=256, num_restarts=4, af_max_iter=8,
+                         seed=0)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.rand(6, dtype=torch.float64, generator=g)    # num_initial_random_samples = 1 (EI needs an incumbent)
+    loop.report(x0, objective(x0))
+    cand = torch.rand(32, 6, dtype=torch.float64, generator=g)
+    for step in range(3):
+        model = loop.model.eval()
+        best_f = float(loop.Y.min())
+        mu_ref, S_ref = _oracle_target_posterior(model, fits, cand)
+        var_ref = S_ref.diagonal()
+        post = model.posterior(cand)
+        torch.testing.assert_close(post.mvn.mean.cpu(), mu_ref, rtol=1e-4, atol=1e-4 * float(mu_ref.abs().max()))
+        torch.testing.assert_close(post.mvn.variance.cpu(), var_ref, rtol=1e-4, atol=1e-4 * float(var_ref.abs().max()))
+        ei = utils.ExpectedImprovement(model, best_f)(cand).cpu()
+        ucb = utils.UpperConfidenceBound(model)(cand).cpu()
+        ei_ref = O.expected_improvement_minimize(mu_ref, var_ref, best_f)
+        ucb_ref = O.ucb_minimize(mu_ref, var_ref)
+        torch.testing.assert_close(ei, ei_ref, rtol=1e-4, atol=1e-4 * float(ei_ref.abs().max()) + 1e-300)
+        torch.testing.assert_close(ucb, ucb_ref, rtol=1e-4, atol=1e-4 * float(ucb_ref.abs().max()))
+        # the loop's own step: the multi-start optimiser's point scores in the top decile of an independent random batch
+        af = loop.acquisition_function()
+        x_next = loop.suggest()
+        assert x_next.shape == (6,) and bool(((x_next >= 0) & (x_next <= 1)).all())
+        assert float(af(x_next.unsqueeze(0))) >= float(af(cand).cpu().quantile(0.9))
+        loop.report(x_next, objective(x_next))
+    assert loop.X.shape == (4, 6) and loop.model.n == 4
+    assert bool((loop.model.weights >= 1e-10).all())
+
+
+def test_optimize_acqf_multistart_finds_known_maximum(device):
+    """The acquisition optimiser on a function with a known maximiser inside the cube and a decoy at a corner."""
+    target = torch.tensor([0.3, 0.7, 0.55], dtype=torch.float64)
+
+    def af(X):
+        X = X.cpu()
+        return torch.exp(-40.0 * ((X - target) ** 2).sum(-1)) + 0.5 * torch.exp(-60.0 * (X ** 2).sum(-1))
+
+    x, v = optimize_acqf(af, 3, raw_samples=128, num_restarts=6, max_iter=40, generator=torch.Generator().manual_seed(0))
+    torch.testing.assert_close(x, target, rtol=0, atol=2e-3)
+    assert float(v) > 0.999

@@ -105,3 +105,37 @@ def test_expanded_distance_under_cancellation(device):
                 torch.testing.assert_close(out["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-7)
                 torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)
                 torch.testing.assert_close(out["L"][t].cpu(), ref["L"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,D", [(32, 200), (64, None), (24, 300)])
+def test_more_dimensions_than_threads(device, N, D):
+    """D above the workgroup's thread count (128 threads at N <= 32, 256 at N <= 64; 64 .. 256 in the posterior
+    kernels): the 1 / lengthscale table has to be filled with a strided loop (round-1 advisor finding: a one-pass fill
+    left invl[blockDim .. D-1] uninitialised and the results silently wrong).  Fit + posterior against the oracle."""
+    from scamlgp_amd import _lib
+    if D is None:
+        D = _lib.lib.scaml_fit_max_d(N)
+        assert D > 256
+    T, M = 3, 20
+    g = torch.Generator().manual_seed(N + D)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g)
+    y = torch.randn(T, N, dtype=torch.float64, generator=g)
+    # distinct lengthscales per dimension: a wrong table entry changes the result
+    ls = (0.5 + torch.rand(T, D, dtype=torch.float64, generator=g)) * D ** 0.5
+    theta = torch.cat([ls, torch.ones(T, 1, dtype=torch.float64), torch.full((T, 1), 1e-3, dtype=torch.float64)], 1)
+    xq = torch.rand(M, D, dtype=torch.float64, generator=g)
+    for kind in (O.KIND_RBF, O.KIND_MATERN52):
+        out = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, want_linv=True)
+        assert not out["info"].cpu().any()
+        post = ops.source_posteriors(xq.to(device), X.to(device), theta.to(device), kind, out["L"], out["Linv_diag"], out["alpha"])
+        Linv = ops.linv_batched(out["L"], out["Linv_diag"])
+        post2 = ops.source_posteriors(xq.to(device), X.to(device), theta.to(device), kind, None, None, out["alpha"], Linv=Linv)
+        for t in range(T):
+            ref = O.gp_fit(X[t], y[t], theta[t], kind)
+            torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=0)
+            torch.testing.assert_close(out["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-4 * float(ref["alpha"].abs().max()))
+            torch.testing.assert_close(out["L"][t].cpu(), ref["L"], rtol=1e-6, atol=1e-9)
+            mu, cov = O.source_posterior(xq, X[t], theta[t], kind, ref["L"], ref["alpha"], 0.0, 1.0)
+            for p in (post, post2):
+                torch.testing.assert_close(p["mean"][t].cpu(), mu, rtol=1e-4, atol=1e-4 * float(mu.abs().max()))
+                torch.testing.assert_close(p["var"][t].cpu(), torch.diagonal(cov), rtol=1e-4, atol=1e-4 * float(cov.abs().max()))

@@ -62,6 +62,47 @@ def test_fit_matches_golden(path, device):
     assert float(torch.triu(out["L"], diagonal=1).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_fit_and_posterior_match_independent_columns(path, device):
+    """The HIP path against the fixtures' scikit-learn / scipy columns (derived without the oracle,
+    tests/golden/make_golden.py): L, alpha, the log marginal likelihood and the predictive mean / covariance on
+    c1 / c2r / c3r / c5r / ragged / N2 and the reference-held inputs; the jitter fixture against scipy's factor of
+    scikit-learn's kernel matrix plus the recorded jitter.  North-star tolerances: 1e-4 alpha / posterior, 1e-3 MLL."""
+    g = np.load(path)
+    kind = int(g["kind"])
+    X, y, theta = (torch.from_numpy(g[k]).to(device) for k in ("X", "y", "theta"))
+    T, N, _ = X.shape
+    npts = torch.from_numpy(g["n_points"]).to(device)
+    ragged = bool((g["n_points"] != N).any())
+    out = ops.gp_fit_fused(X, y, theta, kind, n_points=npts if ragged else None, want_linv=True)
+    assert not out["info"].cpu().any()
+    np.testing.assert_array_equal(out["jitter"].cpu().numpy(), g["jitter"])
+    xq = torch.from_numpy(g["xq"]).to(device)
+    M = xq.shape[0]
+    post = ops.source_posteriors(xq, X, theta, kind, out["L"], out["Linv_diag"], out["alpha"], torch.from_numpy(g["y_mean"]).to(device),
+                                 torch.from_numpy(g["y_std"]).to(device), n_points=npts if ragged else None, cov_first=M)
+    for t in range(T):
+        n = int(g["n_points"][t])
+        tight = g["jitter"][t] == 0.0
+        scale = np.abs(g["sp_L"][t]).max()
+        np.testing.assert_allclose(out["L"][t, :n, :n].cpu().numpy(), g["sp_L"][t, :n, :n], rtol=0, atol=(1e-8 if tight else 1e-4) * scale)
+        np.testing.assert_allclose(float(out["logdet"][t]), g["sp_logdet"][t], rtol=1e-8 if tight else RTOL_MLL, atol=1e-9)
+        if tight:
+            np.testing.assert_allclose(out["alpha"][t, :n].cpu().numpy(), g["sp_alpha"][t, :n], rtol=0,
+                                       atol=RTOL_POST * np.abs(g["sp_alpha"][t]).max())
+        if np.isfinite(g["sk_lml"][t]):
+            np.testing.assert_allclose(out["L"][t, :n, :n].cpu().numpy(), g["sk_L"][t, :n, :n], rtol=0, atol=1e-8 * scale)
+            np.testing.assert_allclose(out["alpha"][t, :n].cpu().numpy(), g["sk_alpha"][t, :n], rtol=0,
+                                       atol=RTOL_POST * np.abs(g["sk_alpha"][t]).max())
+            np.testing.assert_allclose(float(out["mll"][t]) * n, g["sk_lml"][t], rtol=RTOL_MLL)
+            np.testing.assert_allclose(post["mean"][t].cpu().numpy(), g["sk_post_mean"][t], rtol=0,
+                                       atol=RTOL_POST * max(np.abs(g["sk_post_mean"][t]).max(), 1e-300))
+            np.testing.assert_allclose(post["cov"][t].cpu().numpy(), g["sk_post_cov"][t], rtol=0,
+                                       atol=RTOL_POST * np.abs(g["sk_post_cov"][t]).max())
+            np.testing.assert_allclose(post["var"][t].cpu().numpy(), np.diag(g["sk_post_cov"][t]), rtol=0,
+                                       atol=RTOL_POST * np.abs(g["sk_post_cov"][t]).max())
+
+
 @pytest.mark.parametrize("T,N,D,kind", [
     (4, 32, 2, O.KIND_RBF),          # BASELINE config 1 shape
     (64, 128, 2, O.KIND_RBF),        # config 2

@@ -192,6 +192,38 @@ def test_oracle_reproduces_golden(path):
         np.testing.assert_allclose(cov.numpy(), g["post_cov"][t], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_independent_columns(path):
+    """NOT circular: the expected values are the fixture's scikit-learn / scipy columns (tests/golden/make_golden.py,
+    ``independent_columns`` -- no oracle code), the checked values come from the oracle now.  Covers RBF and
+    Matern-5/2 with ARD, the ragged stack, N = 2 / constant-Y tasks, the reference-held inputs (META_DATA_1D +
+    quartic, Forrester family) and, through scipy on scikit-learn's kernel matrix, the jitter-rescued tasks."""
+    g = np.load(path)
+    kind = int(g["kind"])
+    X, y, theta = (torch.from_numpy(g[k]) for k in ("X", "y", "theta"))
+    xq = torch.from_numpy(g["xq"])
+    for t in range(X.shape[0]):
+        n = int(g["n_points"][t])
+        out = O.gp_fit(X[t, :n], y[t, :n], theta[t], kind)
+        jit = float(g["jitter"][t])
+        tight = jit == 0.0
+        scale = np.abs(g["sp_L"][t]).max()
+        # scipy factor / solve of scikit-learn's kernel matrix (+ the recorded jitter)
+        np.testing.assert_allclose(out["L"].numpy(), g["sp_L"][t, :n, :n], rtol=0, atol=(1e-9 if tight else 1e-4) * scale)
+        np.testing.assert_allclose(float(out["logdet"]), g["sp_logdet"][t], rtol=1e-9 if tight else 1e-3, atol=1e-10)
+        if tight:
+            a_scale = np.abs(g["sp_alpha"][t]).max()
+            np.testing.assert_allclose(out["alpha"].numpy(), g["sp_alpha"][t, :n], rtol=0, atol=1e-6 * a_scale)
+        if np.isfinite(g["sk_lml"][t]):
+            # scikit-learn's own factor, weights, log marginal likelihood (un-normalised, prior-free) and predictions
+            np.testing.assert_allclose(out["L"].numpy(), g["sk_L"][t, :n, :n], rtol=0, atol=1e-9 * scale)
+            np.testing.assert_allclose(out["alpha"].numpy(), g["sk_alpha"][t, :n], rtol=0, atol=1e-6 * np.abs(g["sk_alpha"][t]).max())
+            np.testing.assert_allclose(float(out["mll"]) * n, g["sk_lml"][t], rtol=1e-9, atol=1e-9)
+            mu, cov = O.source_posterior(xq, X[t, :n], theta[t], kind, out["L"], out["alpha"], float(g["y_mean"][t]), float(g["y_std"][t]))
+            np.testing.assert_allclose(mu.numpy(), g["sk_post_mean"][t], rtol=0, atol=1e-7 * max(np.abs(g["sk_post_mean"][t]).max(), 1e-300))
+            np.testing.assert_allclose(cov.numpy(), g["sk_post_cov"][t], rtol=0, atol=1e-6 * np.abs(g["sk_post_cov"][t]).max())
+
+
 def test_loop_and_batched_stack_agree():
     g = np.load([p for p in GOLDEN if "c3r" in p][0])
     X, y, theta = (torch.from_numpy(g[k]) for k in ("X", "y", "theta"))
