@@ -8,14 +8,17 @@ two things ``scamlgp/optimizer.py`` does with the model:
              default, utils.py:215-224) over the unit-cube search space.
 
 The acquisition optimiser follows botorch's ``optimize_acqf`` recipe -- ``raw_samples`` random candidates, ``num_restarts``
-initial conditions drawn from them (the best one plus a Boltzmann sample of the rest), a quasi-Newton ascent from every
-start, best end point wins -- but runs all starts in lockstep: one batched L-BFGS whose every objective evaluation is ONE
-batched posterior call over the starts and their central-difference stencils (the HIP posterior has no input-gradient
-kernel), instead of one posterior call per gradient step and start."""
+initial conditions drawn from them (the best one plus a Boltzmann sample of the rest), box-constrained L-BFGS-B over all
+starts jointly, best end point wins -- with every objective evaluation ONE batched posterior call over the starts and
+their central-difference stencils (the HIP posterior has no input-gradient kernel)."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Hashable, Optional, Tuple
 
+import math
+
+import numpy as np
+import scipy.optimize
 import torch
 
 from . import hyper
@@ -24,40 +27,46 @@ from .utils import ExpectedImprovement, UpperConfidenceBound, optimize_marginal_
 
 
 def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samples: int = 1024, num_restarts: int = 10,
-                  max_iter: int = 30, generator: Optional[torch.Generator] = None, fd_step: float = 1e-4,
+                  max_iter: int = 50, generator: Optional[torch.Generator] = None, fd_step: float = 1e-4,
                   eta: float = 2.0) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Maximise ``af`` over [0, 1]^dim by multi-start quasi-Newton ascent; returns (x_best (dim,), af(x_best)).
-    Candidates stay in the cube through x = sigmoid(z); gradients are central differences in x."""
+    """Maximise ``af`` over [0, 1]^dim; returns (x_best (dim,), af(x_best)).  botorch's ``optimize_acqf`` recipe:
+    ``raw_samples`` random candidates -> ``num_restarts`` initial conditions (the best candidate plus a Boltzmann sample
+    of the rest, ``initialize_q_batch``) -> ONE box-constrained L-BFGS-B run over all starts jointly (the summed
+    acquisition value, which is separable over the starts: botorch's ``gen_candidates_scipy`` does the same) -> the
+    best end point.  Every objective evaluation is one batched posterior call over the starts and their
+    central-difference stencils (one-sided at the box faces)."""
     cand = torch.rand(raw_samples, dim, dtype=torch.float64, generator=generator)
     vals = af(cand).detach().cpu()
     R = min(num_restarts, raw_samples)
     best0 = int(vals.argmax())
     picks = [best0]
     if R > 1:
-        # botorch initialize_q_batch: P(i) ~ exp(eta * standardised value), the maximiser always included
         z = (vals - vals.mean()) / vals.std().clamp_min(1e-12)
         pr = torch.exp(eta * (z - z.max()))
         pr[best0] = 0.0
         if float(pr.sum()) > 0:
             k = min(R - 1, int((pr > 0).sum()))
             picks += torch.multinomial(pr, k, replacement=False, generator=generator).tolist()
-    x0 = cand[picks].clamp(1e-6, 1.0 - 1e-6)
+    x0 = cand[picks]
     R = x0.shape[0]
     eye = torch.eye(dim, dtype=torch.float64)
 
-    def fun(zv: torch.Tensor):
-        x = torch.sigmoid(zv.cpu())
-        xp = (x.unsqueeze(1) + fd_step * eye).clamp(0.0, 1.0)      # (R, dim, dim)
+    def fun(zv: np.ndarray):
+        x = torch.from_numpy(zv).reshape(R, dim)
+        xp = (x.unsqueeze(1) + fd_step * eye).clamp(0.0, 1.0)      # (R, dim, dim): start r shifted along dimension d
         xm = (x.unsqueeze(1) - fd_step * eye).clamp(0.0, 1.0)
         v = af(torch.cat([x, xp.reshape(-1, dim), xm.reshape(-1, dim)])).detach().cpu()
-        f = v[:R]
         dx = (xp - xm).diagonal(dim1=1, dim2=2)
         g = (v[R:R + R * dim].reshape(R, dim) - v[R + R * dim:].reshape(R, dim)) / dx
-        return -f, -g * x * (1.0 - x)
+        f = float(v[:R].sum())
+        if not math.isfinite(f):
+            return float("inf"), np.zeros_like(zv)
+        return -f, -torch.nan_to_num(g).reshape(-1).numpy()
 
-    res = hyper.batched_lbfgs(fun, torch.log(x0) - torch.log1p(-x0), max_iter=max_iter, gtol=1e-6)
-    xs = torch.sigmoid(res.x)
-    fin = torch.where(torch.isfinite(res.f), -res.f, torch.full_like(res.f, -float("inf")))
+    res = scipy.optimize.minimize(fun, x0.reshape(-1).numpy(), jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * (R * dim),
+                                  options=dict(maxiter=max_iter))
+    xs = torch.from_numpy(np.clip(res.x, 0.0, 1.0)).reshape(R, dim)
+    fin = torch.nan_to_num(af(xs).detach().cpu(), nan=-float("inf"))
     j = int(fin.argmax())
     if float(fin[j]) >= float(vals[best0]):
         return xs[j], fin[j]
@@ -66,7 +75,7 @@ def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samp
 
 class ScaMLGPBOLoop:
     def __init__(self, source_gps: Dict[Hashable, SourceGP], dim: int, acquisition: str = "ucb", beta: float = 9.0,
-                 num_restarts_log_likelihood: int = 5, raw_samples: int = 1024, num_restarts: int = 10, af_max_iter: int = 30,
+                 num_restarts_log_likelihood: int = 5, raw_samples: int = 1024, num_restarts: int = 10, af_max_iter: int = 50,
                  gp_likelihood: Optional[hyper.GaussianLikelihood] = None, gp_kernel: Optional[hyper.ScaleKernel] = None,
                  seed: Optional[int] = None):
         self.source_gps, self.dim = source_gps, dim

@@ -101,7 +101,7 @@ def test_config4_bo_loop_hartmann6_ei_matches_oracle(device):
     def objective(x):
         return float(synthetic.hartmann6(np.asarray(x, dtype=np.float64).reshape(1, -1), alpha=np.array([1.01, 1.19, 2.9, 3.3]))[0])
 
-    loop = ScaMLGPBOLoop(gps, dim=6, acquisition="ei", num_restarts_log_likelihood=1, raw_samples=256, num_restarts=4, af_max_iter=8,
+    loop = ScaMLGPBOLoop(gps, dim=6, acquisition="ei", num_restarts_log_likelihood=1, raw_samples=256, num_restarts=4, af_max_iter=15,
                          seed=0)
     g = torch.Generator().manual_seed(1)
     x0 = torch.rand(6, dtype=torch.float64, generator=g)    # num_initial_random_samples = 1 (EI needs an incumbent)
@@ -139,6 +139,6 @@ def test_optimize_acqf_multistart_finds_known_maximum(device):
         X = X.cpu()
         return torch.exp(-40.0 * ((X - target) ** 2).sum(-1)) + 0.5 * torch.exp(-60.0 * (X ** 2).sum(-1))
 
-    x, v = optimize_acqf(af, 3, raw_samples=128, num_restarts=6, max_iter=40, generator=torch.Generator().manual_seed(0))
+    x, v = optimize_acqf(af, 3, raw_samples=128, num_restarts=6, max_iter=60, generator=torch.Generator().manual_seed(0))
     torch.testing.assert_close(x, target, rtol=0, atol=2e-3)
     assert float(v) > 0.999
