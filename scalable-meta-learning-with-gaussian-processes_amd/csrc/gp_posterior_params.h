@@ -70,4 +70,15 @@ struct MllGradParams {
   int T, N, D;
 };
 
+struct MllGradFusedParams {
+  const double* X;          // (T, N, D)
+  const double* theta;      // (T, D+2)
+  const double* L;          // (T, N, N) lower factor (strict upper triangle never read)
+  const double* Linv_diag;  // (T, ceil(N/16), 16, 16)
+  const double* alpha;      // (T, N)
+  const int32_t* n_points;  // (T) or NULL
+  double* partials;         // (T, tiles, D+2): the task's totals go into tile slot 0, zeros into the others
+  int T, N, D;
+};
+
 }  // namespace scaml

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 
@@ -22,6 +23,7 @@ extern "C" const unsigned long scaml_hsaco_blob_len;
 namespace {
 
 thread_local char g_last_error[256] = "";
+bool g_force_two_launch_grad = getenv("SCAML_GRAD_LEGACY") != nullptr;   // developer A/B switch (scaml_debug_force_two_launch_grad)
 
 void set_error(const char* what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
@@ -49,6 +51,7 @@ struct Module {
   hipFunction_t kmat[2] = {nullptr, nullptr};
   hipFunction_t chosolve = nullptr;
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
+  hipFunction_t mllgrad_fused[4][2] = {};   // [size class NBT = 2, 4, 8, 16][kind]
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
     if (loaded) return hipSuccess;
@@ -89,6 +92,14 @@ struct Module {
       if ((e = hipFuncSetAttribute((const void*)mllgrad[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)) != hipSuccess) return e;
       snprintf(name, sizeof(name), "_Z23gp_kernel_matrix_kernelILi%dEEvN5scaml18KernelMatrixParamsE", kind);
       if ((e = hipModuleGetFunction(&kmat[kind], mod, name)) != hipSuccess) return e;
+    }
+    for (int sc = 0; sc < 4; ++sc) {
+      for (int kind = 0; kind < 2; ++kind) {
+        char name[128];
+        snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dEEEvNS_18MllGradFusedParamsE", 2 << sc, kind);
+        if ((e = hipModuleGetFunction(&mllgrad_fused[sc][kind], mod, name)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)mllgrad_fused[sc][kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+      }
     }
     loaded = true;
     return hipSuccess;
@@ -416,6 +427,20 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
   const int nb = (N + 15) / 16, nt = nb * (nb + 1) / 2;
   double* Linv = workspace;
   double* partials = partials_out ? partials_out : workspace + (size_t)T * N * N;
+  // N <= 256, D <= 8: ONE launch, one workgroup per task, K^-1 by column strips held in registers; neither L^-1 nor
+  // K^-1 touches memory (csrc/gp_mll_grad_fused.hip).  Larger problems take the two-launch path below.
+  if (N <= 256 && D <= 8 && !g_force_two_launch_grad) {
+    const int sc = N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3));
+    const int nbt = 2 << sc, np = 16 * nbt, nw = nbt / 2;
+    const size_t lds = ((size_t)2 * 16 * (np + 2) + (size_t)np * 9 + np + (size_t)nw * 512 + 64 + 8 + (size_t)nw * 10) * sizeof(double);
+    scaml::MllGradFusedParams p{X, theta, L, Linv_diag, alpha, n_points, partials, T, N, D};
+    size_t psize = sizeof(p);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+    e = hipModuleLaunchKernel(m.mllgrad_fused[sc][kind], (unsigned)T, 1, 1, (unsigned)nbt * 32, 1, 1, (unsigned)lds, (hipStream_t)stream,
+                              nullptr, config);
+    if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad_fused)", e); return SCAML_E_LAUNCH; }
+    return SCAML_OK;
+  }
   {
     const int rc = launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
     if (rc != SCAML_OK) return rc;
@@ -432,6 +457,14 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad)", e); return SCAML_E_LAUNCH; }
   }
   return SCAML_OK;
+}
+
+// Developer switch: route scaml_mll_backward_f64 through the two-launch path (L^-1 in the workspace, then the K^-1 tile
+// kernel) even where the single-launch kernel applies -- for A/B timing and for testing one path against the other.
+int scaml_debug_force_two_launch_grad(int on) {
+  const int was = g_force_two_launch_grad ? 1 : 0;
+  g_force_two_launch_grad = on != 0;
+  return was;
 }
 
 // Diagnostic builds only (SCAML_STAMPS): point the device-side stamp buffer at caller memory.

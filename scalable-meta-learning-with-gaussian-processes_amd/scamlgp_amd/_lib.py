@@ -96,6 +96,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_mll_backward_workspace_doubles.argtypes = [c_int, c_int, c_int]
     lib.scaml_mll_backward_f64.restype = c_int
     lib.scaml_mll_backward_f64.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, _dp, _dp, c_void_p]
+    lib.scaml_debug_force_two_launch_grad.restype = c_int
+    lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib
 
 

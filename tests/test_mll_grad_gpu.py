@@ -33,6 +33,10 @@ def _autograd_grad(X, y, theta, kind):
     (2, 512, 6, O.KIND_RBF),
     (2, 72, 40, O.KIND_MATERN52),   # large D: the staged points of a wave's four blocks need > 64 KB of LDS per workgroup
     (3, 16, 1, O.KIND_RBF),         # one block: a super-tile with three absent tiles
+    (5, 200, 8, O.KIND_MATERN52),   # N not a multiple of 16 in the largest single-launch size class
+    (4, 129, 7, O.KIND_RBF),        # first size past a class boundary: mostly padding
+    (3, 64, 8, O.KIND_MATERN52),
+    (2, 256, 9, O.KIND_MATERN52),   # D > 8: the two-launch path
 ])
 def test_mll_gradient_matches_autograd(T, N, D, kind, device):
     d = synthetic.smooth_field_task_stack(T, N, D, seed=20 + N)
@@ -41,12 +45,23 @@ def test_mll_gradient_matches_autograd(T, N, D, kind, device):
     theta = torch.from_numpy(np.concatenate([0.5 * (1 + 0.6 * (rng.uniform(size=(T, D)) - 0.5)), 0.8 + 0.4 * rng.uniform(size=(T, 1)),
                                              np.full((T, 1), 2e-3)], 1))
     X, y = torch.from_numpy(d["X"]), torch.from_numpy(ys)
-    fit = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, want_linv=True)
+    # zero_upper=False: what the optimiser loop passes -- the strict upper triangle of L is never read
+    fit = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, want_linv=True, zero_upper=N > 256)
+    if N <= 256:
+        fit["L"] = fit["L"] + torch.triu(torch.full_like(fit["L"], float("nan")), diagonal=1)
     g = ops.mll_backward(X.to(device), theta.to(device), kind, fit["L"], fit["Linv_diag"], fit["alpha"]).cpu()
     for t in range(T):
         ref = _autograd_grad(X[t], y[t], theta[t], kind)
         # gradient entries span orders of magnitude (the noise derivative is ~1e3 larger): compare per entry
         torch.testing.assert_close(g[t], ref, rtol=1e-6, atol=1e-9 * float(ref.abs().max()))
+    # the single-launch kernel (N <= 256, D <= 8) and the two-launch path (L^-1 in memory) agree
+    from scamlgp_amd import _lib
+    was = _lib.lib.scaml_debug_force_two_launch_grad(1)
+    try:
+        g2 = ops.mll_backward(X.to(device), theta.to(device), kind, torch.tril(torch.nan_to_num(fit["L"])), fit["Linv_diag"], fit["alpha"]).cpu()
+    finally:
+        _lib.lib.scaml_debug_force_two_launch_grad(was)
+    torch.testing.assert_close(g, g2, rtol=1e-8, atol=1e-11 * float(g2.abs().max()))
 
 
 def test_mll_gradient_ragged(device):
