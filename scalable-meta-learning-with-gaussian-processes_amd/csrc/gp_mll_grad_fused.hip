@@ -41,7 +41,16 @@ constexpr int GF_DMAX = 8;
 // separates the last MFMA writing a register from any non-accumulating read of it (as MFMA A/B operand,
 // v_accvgpr_read, VALU); dependent accumulation into the same registers issues back to back (interlocked).
 #include "tile_regs.inc"
+#ifdef GF_NO_DRAIN   // (timing experiments only: the results are wrong without the wait states)
+#define GF_DRAIN() asm volatile("" ::: "memory")
+#else
 #define GF_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
+#endif
+#ifdef GF_NO_MFMA    // (timing experiments only: everything but the matrix instructions)
+#define GF_MFMA(txt) "; " txt
+#else
+#define GF_MFMA(txt) txt
+#endif
 
 // The accumulator of a strip step is a block of its own, slot 17 = a[136:143] ("ACC"): compiler-visible VGPR
 // accumulators were copied around by VALU moves right behind the asm MFMAs (stale reads of the last result pair).
@@ -64,10 +73,11 @@ struct GfTile;
     /* ACC -= A * block, the block as B operand (k-step m reads register pair m) */                                \
     static __device__ __forceinline__ void chain_neg(double a0, double a1, double a2, double a3) {                 \
       asm volatile("s_nop 1\n\t"                                                                                   \
-                   "v_mfma_f64_16x16x4_f64 " GF_ACC ", %0, a[" #r0 ":" #r1 "], " GF_ACC " neg:[1,0,0]\n\t"         \
-                   "v_mfma_f64_16x16x4_f64 " GF_ACC ", %1, a[" #r2 ":" #r3 "], " GF_ACC " neg:[1,0,0]\n\t"         \
-                   "v_mfma_f64_16x16x4_f64 " GF_ACC ", %2, a[" #r4 ":" #r5 "], " GF_ACC " neg:[1,0,0]\n\t"         \
-                   "v_mfma_f64_16x16x4_f64 " GF_ACC ", %3, a[" #r6 ":" #r7 "], " GF_ACC " neg:[1,0,0]"              \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 " GF_ACC ", %0, a[" #r0 ":" #r1 "], " GF_ACC " neg:[1,0,0]\n\t") \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 " GF_ACC ", %1, a[" #r2 ":" #r3 "], " GF_ACC " neg:[1,0,0]\n\t") \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 " GF_ACC ", %2, a[" #r4 ":" #r5 "], " GF_ACC " neg:[1,0,0]\n\t") \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 " GF_ACC ", %3, a[" #r6 ":" #r7 "], " GF_ACC " neg:[1,0,0]\n\t") \
+                   "s_nop 0"                                                                                       \
                    :                                                                                               \
                    : "v"(a0), "v"(a1), "v"(a2), "v"(a3)                                                            \
                    : "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143");                              \
@@ -75,10 +85,10 @@ struct GfTile;
     /* block = A * ACC (the caller has drained the MFMAs that wrote ACC) */                                        \
     static __device__ __forceinline__ void set_prod_acc(double a0, double a1, double a2, double a3) {              \
       asm volatile("s_nop 1\n\t"                                                                                   \
-                   "v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %0, a[136:137], 0\n\t"                              \
-                   "v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %1, a[138:139], a[" #r0 ":" #r7 "]\n\t"             \
-                   "v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %2, a[140:141], a[" #r0 ":" #r7 "]\n\t"             \
-                   "v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %3, a[142:143], a[" #r0 ":" #r7 "]\n\t"             \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %0, a[136:137], 0\n\t")                     \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %1, a[138:139], a[" #r0 ":" #r7 "]\n\t")    \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %2, a[140:141], a[" #r0 ":" #r7 "]\n\t")    \
+                   GF_MFMA("v_mfma_f64_16x16x4_f64 a[" #r0 ":" #r7 "], %3, a[142:143], a[" #r0 ":" #r7 "]\n\t")    \
                    "s_nop 7"                                                                                       \
                    :                                                                                               \
                    : "v"(a0), "v"(a1), "v"(a2), "v"(a3)                                                            \
@@ -239,7 +249,78 @@ __device__ __forceinline__ void gf_kernel_and_dfactor(double d2, const double* e
     }                                                                    \
     break;
 
-template <int NBT, int KIND>
+// value of an MFMA result for the VALU: 19 wait states behind the instruction (hipcc pads for the 8-pass gfx942
+// instruction; on gfx950 the last result pair is not interlocked), and the data dependency keeps the uses behind it
+__device__ __forceinline__ d4_t gf_settle(d4_t v) {
+  asm volatile("s_nop 15\n\ts_nop 2" : "+v"(v));
+  return v;
+}
+
+// Per-strip state of the gradient epilogue: T accumulates [X_a^T; (X_a^2)^T] GH over the strip's blocks (rows 0..7: sum_a
+// x_ad GH_ac, rows 8..15: sum_a x_ad^2 GH_ac, column c on the lane), cs the lane's share of the column sums of GH.
+struct GfStrip {
+  d4_t T;
+  double cs;
+};
+
+// Gradient contributions of the finished K^-1 block (kb, c) (register image `zt`, lane-owned): G = alpha alpha^T - K^-1,
+// GH = G os h;  sum G k -> g_os, tr G -> g_noise, and for the lengthscales
+//   sum_ac GH_ac (x_ad - x_cd)^2 = sum_c [ Q2_dc - 2 x_cd Q_dc + x_cd^2 CS_c ]
+// with Q = X_a^T GH, Q2 = (X_a^2)^T GH accumulated on the matrix core (GH in the C/D layout IS the B operand) and the
+// squared distances of the block from one MFMA chain as well (expanded form, norms as a third k-step): the VALU is left
+// with the kernel function and G.  At the strip's last block (kb == c) the sums over a are complete and folded into the
+// lane's two lengthscale partials (dimensions lq and lq + 4).
+template <int KIND>
+__device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int kb, int c, int n, const double* Xs, const double* als,
+                                            const double* exptab, double os, double& g_os, double& g_noise, double& pd0,
+                                            double& pd1, int lc, int lq) {
+  const int col = 16 * c + lc;
+  const double* xcp = Xs + col * GF_DP;
+  const double* xap = Xs + (16 * kb + lc) * GF_DP;
+  const double xc0 = xcp[lq], xc1 = xcp[lq + 4];           // B operand of the distance product: X_c[d = lq + 4 m][point lc]
+  const double nc = xcp[8], na = xap[8];
+  d4_t d2v = {0.0, 0.0, 0.0, 0.0};
+  d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(-2.0 * xap[lq], xc0, d2v, 0, 0, 0);
+  d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(-2.0 * xap[lq + 4], xc1, d2v, 0, 0, 0);
+  d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(lq == 0 ? na : (lq == 1 ? 1.0 : 0.0), lq == 0 ? 1.0 : (lq == 1 ? nc : 0.0), d2v, 0, 0, 0);
+  d2v = gf_settle(d2v);
+  const double wgt = kb == c ? 1.0 : 2.0;   // off-diagonal blocks stand for both triangles
+  const double ac = als[col];
+  d4_t GH;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = 16 * kb + lq + 4 * g;
+    double d2 = d2v[g] > 0.0 ? d2v[g] : 0.0;
+    if (row == col) d2 = 0.0;
+    double k, h;
+    gf_kernel_and_dfactor<KIND>(d2, exptab, k, h);
+    const bool ok = row < n && col < n;
+    const double Gv = ok ? wgt * (als[row] * ac - zt[64 * g]) : 0.0;
+    GH[g] = Gv * os * h;
+    g_os = __builtin_fma(Gv, k, g_os);
+    if (row == col) g_noise += Gv;
+    st.cs += GH[g];
+  }
+  // T += [X_a^T; (X_a^2)^T] GH: A[i = lc][k = lq + 4 m] = x_{a, k}[d = lc & 7], squared for the rows i >= 8
+  const double* xk = Xs + (16 * kb + lq) * GF_DP + (lc & 7);
+  const bool sq = lc >= 8;
+  d4_t T = st.T;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const double v = xk[4 * m * GF_DP];
+    T = __builtin_amdgcn_mfma_f64_16x16x4f64(sq ? v * v : v, GH[m], T, 0, 0, 0);
+  }
+  st.T = T;
+  if (kb == c) {
+    const d4_t Tf = gf_settle(T);
+    const double cscol = sum_lane_groups(st.cs);   // column sum over all rows of the strip
+    // lane (lc, lq): rows lq, lq + 4 of Q (registers 0, 1) and of Q2 (registers 2, 3)
+    pd0 += Tf[2] - 2.0 * xc0 * Tf[0] + xc0 * xc0 * cscol;
+    pd1 += Tf[3] - 2.0 * xc1 * Tf[1] + xc1 * xc1 * cscol;
+  }
+}
+
+template <int NBT, int KIND, bool DMA>
 __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFusedParams p) {
   constexpr int NP = 16 * NBT;
   constexpr int PA = NP + 2;             // pitch of a staged row block: lc * PA + lq hits 32 different 8-byte banks
@@ -248,7 +329,7 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
   constexpr int BUF = 16 * PA;           // doubles per staging buffer (a column block, NP x 16, fits as well)
   extern __shared__ double lds[];
   double* buf = lds;                     // [2][BUF]
-  double* Xs = buf + 2 * BUF;            // [NP][GF_DP] points scaled by 1 / lengthscale, zero-padded to 8 dimensions
+  double* Xs = buf + 2 * BUF;            // [NP][GF_DP] points scaled by 1 / lengthscale, zero-padded to 8 dimensions; [8] = |x|^2
   double* als = Xs + NP * GF_DP;         // [NP] alpha (0 past n)
   double* zs_all = als + NP;             // [NW][2][256] finished K^-1 blocks (register images)
   double* exptab = zs_all + NW * 512;    // [64]
@@ -272,101 +353,155 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
   const int kp = (NW < 2 || wave < NW / 2) ? wave : (NW + NW / 2 - 1 - wave);
   const int cA = kp, cB = NBT - 1 - kp;
 
-  // ---- staging of one step's slice of L: registers now, LDS one step later
-  double stg[8];
-  const bool n_even = (N & 1) == 0;
-  auto load_step = [&](int t) {   // t < NB: row block t (forward);  else column block 2 NB - 1 - t (backward)
+  // ---- staging of one step's slice of L (t < NB: row block t, forward; else column block 2 NB - 1 - t, backward) with
+  // the inverse W of the diagonal block in place of the diagonal block itself.
+  // DMA (the host picks it when N is a multiple of 16 and the stack is not ragged, so that no element needs masking):
+  // global_load_lds_dwordx4 -- each wave-instruction moves 64 x 16 B from per-lane addresses to 1 KB of consecutive LDS,
+  // no VGPRs, no LDS-write pass; issued at the start of step t for step t + 1, waited for (vmcnt) before the barrier that
+  // ends step t.  Otherwise: registers now, LDS one step later (masked loads).
+  typedef __attribute__((address_space(1))) void gvoid_t;
+  typedef __attribute__((address_space(3))) void lvoid_t;
+  auto dma_step = [&](int t) {
+    double* b = buf + (t & 1) * BUF;
     if (t < NB) {
-      const int kb = t, r = tid / (2 * NBT), ch = tid % (2 * NBT);
-      const int row = 16 * kb + r, col0 = 8 * ch;
-      if (col0 < 16 * kb) {
-        const double* src = Lg + (size_t)row * N + col0;
-        if (n_even && row < n && col0 + 8 <= n) {
+      const int kb = t;
+      constexpr int RPW = 16 / NW;                 // rows per wave
+      const int nch = 8 * kb + 8;                  // 16-byte pieces per row: 16 kb columns of L, then the 16 of W_kb
 #pragma unroll
-          for (int q = 0; q < 8; q += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(src + q);
-            stg[q] = v.x; stg[q + 1] = v.y;
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int r = wave * RPW + rr;
+        const double* lrow = Lg + (size_t)(16 * kb + r) * N;
+        const double* wrow = Wg + (size_t)kb * 256 + r * 16 - 16 * kb;
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+          const int ch = c0 + lane;
+          if (ch < nch) {
+            const double* src = (ch < 8 * kb ? lrow : wrow) + 2 * ch;
+            __builtin_amdgcn_global_load_lds((const gvoid_t*)src, (lvoid_t*)(b + r * PA + 2 * c0), 16, 0, 0);
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) stg[q] = (row < n && col0 + q < n) ? src[q] : 0.0;
-        }
-      } else if (col0 < 16 * kb + 16) {
-        const double* src = Wg + (size_t)kb * 256 + r * 16 + (col0 - 16 * kb);
-#pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          const double2 v = *reinterpret_cast<const double2*>(src + q);
-          stg[q] = v.x; stg[q + 1] = v.y;
         }
       }
     } else if (t < 2 * NB) {
-      const int kb = 2 * NB - 1 - t, row = tid >> 1, c8 = 8 * (tid & 1);
-      if (row >= 16 * kb + 16) {
-        const int col0 = 16 * kb + c8;
-        const double* src = Lg + (size_t)row * N + col0;
-        if (n_even && row < n) {   // (col0 + 8 <= 16 kb + 16 <= row < n)
+      const int kb = 2 * NB - 1 - t;
+      // rows 16 kb .. 16 NB - 1 of the column block, 8 rows (128 B each) per wave-instruction, dealt to the waves in turn
+      for (int r0 = 16 * kb + 8 * wave; r0 < 16 * NB; r0 += 8 * NW) {
+        const int row = r0 + (lane >> 3), c2 = 2 * (lane & 7);
+        const double* src = row < 16 * kb + 16 ? Wg + (size_t)kb * 256 + (row - 16 * kb) * 16 + c2 : Lg + (size_t)row * N + 16 * kb + c2;
+        __builtin_amdgcn_global_load_lds((const gvoid_t*)src, (lvoid_t*)(b + r0 * 16), 16, 0, 0);
+      }
+    }
+  };
+  double stg[DMA ? 1 : 8];
+  const bool n_even = (N & 1) == 0;
+  auto load_step = [&](int t) {
+    if constexpr (!DMA) {
+      if (t < NB) {
+        const int kb = t, r = tid / (2 * NBT), ch = tid % (2 * NBT);
+        const int row = 16 * kb + r, col0 = 8 * ch;
+        if (col0 < 16 * kb) {
+          const double* src = Lg + (size_t)row * N + col0;
+          if (n_even && row < n && col0 + 8 <= n) {
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+              const double2 v = *reinterpret_cast<const double2*>(src + q);
+              stg[q] = v.x; stg[q + 1] = v.y;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stg[q] = (row < n && col0 + q < n) ? src[q] : 0.0;
+          }
+        } else if (col0 < 16 * kb + 16) {
+          const double* src = Wg + (size_t)kb * 256 + r * 16 + (col0 - 16 * kb);
 #pragma unroll
           for (int q = 0; q < 8; q += 2) {
             const double2 v = *reinterpret_cast<const double2*>(src + q);
             stg[q] = v.x; stg[q + 1] = v.y;
           }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) stg[q] = (row < n && col0 + q < n) ? src[q] : 0.0;
         }
-      } else if (row >= 16 * kb) {
-        const double* src = Wg + (size_t)kb * 256 + (row - 16 * kb) * 16 + c8;
+      } else if (t < 2 * NB) {
+        const int kb = 2 * NB - 1 - t, row = tid >> 1, c8 = 8 * (tid & 1);
+        if (row >= 16 * kb + 16) {
+          const int col0 = 16 * kb + c8;
+          const double* src = Lg + (size_t)row * N + col0;
+          if (n_even && row < n) {   // (col0 + 8 <= 16 kb + 16 <= row < n)
 #pragma unroll
-        for (int q = 0; q < 8; q += 2) {
-          const double2 v = *reinterpret_cast<const double2*>(src + q);
-          stg[q] = v.x; stg[q + 1] = v.y;
+            for (int q = 0; q < 8; q += 2) {
+              const double2 v = *reinterpret_cast<const double2*>(src + q);
+              stg[q] = v.x; stg[q + 1] = v.y;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stg[q] = (row < n && col0 + q < n) ? src[q] : 0.0;
+          }
+        } else if (row >= 16 * kb) {
+          const double* src = Wg + (size_t)kb * 256 + (row - 16 * kb) * 16 + c8;
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(src + q);
+            stg[q] = v.x; stg[q + 1] = v.y;
+          }
         }
       }
     }
   };
   auto store_step = [&](int t) {
-    double* b = buf + (t & 1) * BUF;
-    if (t < NB) {
-      const int kb = t, r = tid / (2 * NBT), ch = tid % (2 * NBT);
-      if (8 * ch < 16 * kb + 16) {
-        double* dst = b + r * PA + 8 * ch;
+    if constexpr (!DMA) {
+      double* b = buf + (t & 1) * BUF;
+      if (t < NB) {
+        const int kb = t, r = tid / (2 * NBT), ch = tid % (2 * NBT);
+        if (8 * ch < 16 * kb + 16) {
+          double* dst = b + r * PA + 8 * ch;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q] = stg[q];
-      }
-    } else if (t < 2 * NB) {
-      const int kb = 2 * NB - 1 - t, row = tid >> 1;
-      if (row >= 16 * kb) {
-        double* dst = b + row * 16 + 8 * (tid & 1);
+          for (int q = 0; q < 8; ++q) dst[q] = stg[q];
+        }
+      } else if (t < 2 * NB) {
+        const int kb = 2 * NB - 1 - t, row = tid >> 1;
+        if (row >= 16 * kb) {
+          double* dst = b + row * 16 + 8 * (tid & 1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q] = stg[q];
+          for (int q = 0; q < 8; ++q) dst[q] = stg[q];
+        }
       }
     }
   };
 
-  load_step(0);
+  if constexpr (DMA) dma_step(0); else load_step(0);
   exp2_table_init(exptab, tid);
   if (tid < GF_DMAX) invl[tid] = tid < D ? 1.0 / th[tid] : 0.0;
   __syncthreads();
-  for (int e = tid; e < NP * GF_DP; e += TPB) {
-    const int r = e / GF_DP, d = e - r * GF_DP;
-    Xs[e] = (r < n && d < D) ? p.X[((size_t)task * N + r) * D + d] * invl[d] : 0.0;
+  for (int r = tid; r < NP; r += TPB) {
+    double nrm = 0.0;
+#pragma unroll
+    for (int d = 0; d < GF_DMAX; ++d) {
+      const double v = (r < n && d < D) ? p.X[((size_t)task * N + r) * D + d] * invl[d] : 0.0;
+      Xs[r * GF_DP + d] = v;
+      nrm = __builtin_fma(v, v, nrm);
+    }
+    Xs[r * GF_DP + 8] = nrm;
+    als[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
   }
-  for (int r = tid; r < NP; r += TPB) als[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
-  store_step(0);
-  load_step(1);
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    store_step(0);
+    load_step(1);
+  }
   __syncthreads();
 
-  double accd[GF_DMAX];
-#pragma unroll
-  for (int d = 0; d < GF_DMAX; ++d) accd[d] = 0.0;
-  double g_os = 0.0, g_noise = 0.0;
+  GfStrip stA = {d4_t{0.0, 0.0, 0.0, 0.0}, 0.0}, stB = stA;
+  double g_os = 0.0, g_noise = 0.0, pd0 = 0.0, pd1 = 0.0;
   double* zs = zs_all + wave * 512;
 
   for (int t = 0; t < 2 * NB; ++t) {
-    // the slice for step t + 1 (loaded during step t - 1) goes into the buffer step t - 1 read from: everybody is past
-    // the barrier that ended it; then the loads for step t + 2 start and have this whole step to land
-    store_step(t + 1);
-    load_step(t + 2);
+#ifndef GF_NO_STAGE
+    if constexpr (DMA) {
+      dma_step(t + 1);   // into the buffer step t - 1 read from: everybody is past the barrier that ended it
+    } else {
+      // the slice for step t + 1 (loaded during step t - 1) goes into the buffer step t - 1 read from; then the loads for
+      // step t + 2 start and have this whole step to land
+      store_step(t + 1);
+      load_step(t + 2);
+    }
+#endif
     const bool fwd = t < NB;
     const int kb = fwd ? t : 2 * NB - 1 - t;
     const double* b = buf + (t & 1) * BUF;
@@ -378,52 +513,23 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
       GF_STEP_CASE(14) GF_STEP_CASE(15)
       default: break;
     }
+#ifndef GF_NO_EPI
     if (!fwd) {
-      // ---- gradient epilogue for the K^-1 blocks (kb, cA) / (kb, cB) just finished: this lane owns rows
-      // 16 kb + lq + 4 g, column 16 c + lc
-      for (int s = 0; s < 2; ++s) {
-        const int c = s ? cB : cA;
-        if (kb < c) continue;
-        const double* zt = zs + s * 256 + lane;
-        const int col = 16 * c + lc;
-        const double wgt = kb == c ? 1.0 : 2.0;   // off-diagonal blocks stand for both triangles
-        double xc[GF_DMAX];
-#pragma unroll
-        for (int d = 0; d < GF_DMAX; ++d) xc[d] = Xs[col * GF_DP + d];
-        const double ac = als[col];
-#pragma clang loop unroll(disable)
-        for (int g = 0; g < 4; ++g) {   // (rolled: four unrolled copies cost ~90 more live registers than the cap leaves)
-          const int row = 16 * kb + lq + 4 * g;
-          const double* xr = Xs + row * GF_DP;
-          double d2 = 0.0;
-#pragma unroll
-          for (int d = 0; d < GF_DMAX; ++d) {
-            const double df = xr[d] - xc[d];
-            d2 = __builtin_fma(df, df, d2);
-          }
-          double k, h;
-          gf_kernel_and_dfactor<KIND>(d2, exptab, k, h);
-          const bool ok = row < n && col < n;
-          const double Gv = ok ? wgt * (als[row] * ac - zt[64 * g]) : 0.0;
-          const double GH = Gv * os * h;
-          g_os = __builtin_fma(Gv, k, g_os);
-          if (row == col) g_noise += Gv;
-#pragma unroll
-          for (int d = 0; d < GF_DMAX; ++d) {
-            const double df = xr[d] - xc[d];
-            accd[d] = __builtin_fma(GH, df * df, accd[d]);
-          }
-        }
-      }
+      if (kb >= cA) gf_epilogue<KIND>(stA, zs + lane, kb, cA, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
+      if (kb >= cB) gf_epilogue<KIND>(stB, zs + 256 + lane, kb, cB, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
     }
+#endif
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice have landed
     __syncthreads();
   }
 
-  // ---- D + 2 sums: over the wave, then over the waves in a fixed order; the task's totals go into tile slot 0
-#pragma unroll
-  for (int d = 0; d < GF_DMAX; ++d) {
-    const double s = wave_sum_to_lane15(accd[d] * invl[d]);
-    if (lane == 63) red[wave * 10 + d] = s;
+  // ---- D + 2 sums: lengthscale partials over the 16 columns of a lane group (dimensions lq, lq + 4), the two scalars over
+  // the wave; then over the waves in a fixed order; the task's totals go into tile slot 0
+  pd0 = row_sum_to_lane15(pd0);
+  pd1 = row_sum_to_lane15(pd1);
+  if (lc == 15) {
+    red[wave * 10 + lq] = pd0 * invl[lq];
+    red[wave * 10 + lq + 4] = pd1 * invl[lq + 4];
   }
   g_os = wave_sum_to_lane15(g_os);
   g_noise = wave_sum_to_lane15(g_noise);
@@ -443,9 +549,11 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
 
 }  // namespace scaml
 
-#define SCAML_INSTANTIATE_GF(NBT)                                                                   \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0>(scaml::MllGradFusedParams);     \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1>(scaml::MllGradFusedParams);
+#define SCAML_INSTANTIATE_GF(NBT)                                                                          \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, false>(scaml::MllGradFusedParams);     \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, false>(scaml::MllGradFusedParams);     \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, true>(scaml::MllGradFusedParams);      \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, true>(scaml::MllGradFusedParams);
 SCAML_INSTANTIATE_GF(2)
 SCAML_INSTANTIATE_GF(4)
 SCAML_INSTANTIATE_GF(8)

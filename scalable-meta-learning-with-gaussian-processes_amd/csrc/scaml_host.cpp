@@ -51,7 +51,7 @@ struct Module {
   hipFunction_t kmat[2] = {nullptr, nullptr};
   hipFunction_t chosolve = nullptr;
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
-  hipFunction_t mllgrad_fused[4][2] = {};   // [size class NBT = 2, 4, 8, 16][kind]
+  hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
     if (loaded) return hipSuccess;
@@ -95,10 +95,12 @@ struct Module {
     }
     for (int sc = 0; sc < 4; ++sc) {
       for (int kind = 0; kind < 2; ++kind) {
-        char name[128];
-        snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dEEEvNS_18MllGradFusedParamsE", 2 << sc, kind);
-        if ((e = hipModuleGetFunction(&mllgrad_fused[sc][kind], mod, name)) != hipSuccess) return e;
-        if ((e = hipFuncSetAttribute((const void*)mllgrad_fused[sc][kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        for (int dma = 0; dma < 2; ++dma) {
+          char name[128];
+          snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dELb%dEEEvNS_18MllGradFusedParamsE", 2 << sc, kind, dma);
+          if ((e = hipModuleGetFunction(&mllgrad_fused[sc][kind][dma], mod, name)) != hipSuccess) return e;
+          if ((e = hipFuncSetAttribute((const void*)mllgrad_fused[sc][kind][dma], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        }
       }
     }
     loaded = true;
@@ -436,7 +438,9 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     scaml::MllGradFusedParams p{X, theta, L, Linv_diag, alpha, n_points, partials, T, N, D};
     size_t psize = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-    e = hipModuleLaunchKernel(m.mllgrad_fused[sc][kind], (unsigned)T, 1, 1, (unsigned)nbt * 32, 1, 1, (unsigned)lds, (hipStream_t)stream,
+    // direct-to-LDS staging moves raw 16-byte pieces: only where no element needs masking and every row is 16-byte aligned
+    const int dma = (n_points == nullptr && N % 16 == 0 && ((uintptr_t)L % 16) == 0 && ((uintptr_t)Linv_diag % 16) == 0) ? 1 : 0;
+    e = hipModuleLaunchKernel(m.mllgrad_fused[sc][kind][dma], (unsigned)T, 1, 1, (unsigned)nbt * 32, 1, 1, (unsigned)lds, (hipStream_t)stream,
                               nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad_fused)", e); return SCAML_E_LAUNCH; }
     return SCAML_OK;
