@@ -136,16 +136,29 @@ SCAML_TILE_LIST(GF_DEF_TILE)
 template <int NBT, bool SB>
 __device__ __forceinline__ constexpr int gf_slot(int j) { return SB ? j + 1 : NBT - 1 - j; }
 
-// forward: acc -= sum_{j = c}^{KB-1} L[KB][j] V_j, entered at the run-time first block c and falling through
+// A operands of one block product (four k-steps)
+struct GfOps {
+  double a0, a1, a2, a3;
+};
+__device__ __forceinline__ GfOps gf_load_ops(const double* q, int stride) {
+  GfOps o = {q[0], q[stride], q[2 * stride], q[3 * stride]};
+  return o;
+}
+
+// forward: ACC -= sum_{j = c}^{KB-1} L[KB][j] V_j, entered at the run-time first block c and falling through.  The
+// operands of product j + 1 are read from LDS before the MFMAs of product j are issued (every case is a basic block
+// of its own: without this each product would expose an LDS round trip); after the last product `cur` holds the
+// operands at block column KB -- W_KB, what the closing product needs.
 #define GF_FWD_CASE(J)                                                                                  \
   case J:                                                                                               \
     if constexpr (J < KB && J < NBT) {                                                                  \
-      const double* q = pa + 16 * J;                                                                    \
-      GfTile<gf_slot<NBT, SB>(J < NBT ? J : 0)>::chain_neg(q[0], q[4], q[8], q[12]);               \
+      const GfOps nxt = gf_load_ops(pa + 16 * (J + 1), 4);                                              \
+      GfTile<gf_slot<NBT, SB>(J < NBT ? J : 0)>::chain_neg(cur.a0, cur.a1, cur.a2, cur.a3);             \
+      cur = nxt;                                                                                        \
     }                                                                                                   \
     [[fallthrough]];
 template <int KB, int NBT, bool SB>
-__device__ __forceinline__ void gf_fwd_chain(int c, const double* pa) {
+__device__ __forceinline__ void gf_fwd_chain(GfOps& cur, int c, const double* pa) {
   switch (c) {
     GF_FWD_CASE(0) GF_FWD_CASE(1) GF_FWD_CASE(2) GF_FWD_CASE(3) GF_FWD_CASE(4) GF_FWD_CASE(5) GF_FWD_CASE(6) GF_FWD_CASE(7)
     GF_FWD_CASE(8) GF_FWD_CASE(9) GF_FWD_CASE(10) GF_FWD_CASE(11) GF_FWD_CASE(12) GF_FWD_CASE(13) GF_FWD_CASE(14)
@@ -154,16 +167,18 @@ __device__ __forceinline__ void gf_fwd_chain(int c, const double* pa) {
 }
 #undef GF_FWD_CASE
 
-// backward: acc -= sum_{j = KB+1}^{NB-1} L[j][KB]^T Z_j, entered at the run-time last block NB-1 and falling through
+// backward: ACC -= sum_{j = KB+1}^{NB-1} L[j][KB]^T Z_j, entered at the run-time last block NB-1 and falling through
+// (descending; the read-ahead ends on block KB: W_KB^T)
 #define GF_BWD_CASE(J)                                                                                  \
   case J:                                                                                               \
     if constexpr (J > KB && J < NBT) {                                                                  \
-      const double* q = pb + 16 * J * 16;                                                               \
-      GfTile<gf_slot<NBT, SB>(J < NBT ? J : 0)>::chain_neg(q[0], q[64], q[128], q[192]);           \
+      const GfOps nxt = gf_load_ops(pb + 16 * (J - 1) * 16, 64);                                        \
+      GfTile<gf_slot<NBT, SB>(J < NBT ? J : 0)>::chain_neg(cur.a0, cur.a1, cur.a2, cur.a3);             \
+      cur = nxt;                                                                                        \
     }                                                                                                   \
     [[fallthrough]];
 template <int KB, int NBT, bool SB>
-__device__ __forceinline__ void gf_bwd_chain(int last, const double* pb) {
+__device__ __forceinline__ void gf_bwd_chain(GfOps& cur, int last, const double* pb) {
   switch (last) {
     GF_BWD_CASE(15) GF_BWD_CASE(14) GF_BWD_CASE(13) GF_BWD_CASE(12) GF_BWD_CASE(11) GF_BWD_CASE(10) GF_BWD_CASE(9)
     GF_BWD_CASE(8) GF_BWD_CASE(7) GF_BWD_CASE(6) GF_BWD_CASE(5) GF_BWD_CASE(4) GF_BWD_CASE(3) GF_BWD_CASE(2) GF_BWD_CASE(1)
@@ -182,13 +197,12 @@ __device__ __forceinline__ void gf_fwd_strip(int c, const double* pa, int PA, in
     Dst::set(w[0], w[4 * PA], w[8 * PA], w[12 * PA]);
     return;
   }
+  GfOps cur = gf_load_ops(pa + 16 * c, 4);
   GF_DRAIN();        // (the previous strip step's last MFMA may still be reading ACC)
   gf_acc_zero();
-  gf_fwd_chain<KB, NBT, SB>(c, pa);
-  const double* q = pa + 16 * KB;   // (W_KB sits in the staged row block's last 16 columns)
-  const double w0 = q[0], w1 = q[4], w2 = q[8], w3 = q[12];
+  gf_fwd_chain<KB, NBT, SB>(cur, c, pa);
   GF_DRAIN();
-  Dst::set_prod_acc(w0, w1, w2, w3);
+  Dst::set_prod_acc(cur.a0, cur.a1, cur.a2, cur.a3);   // (W_KB sits in the staged row block's last 16 columns)
 }
 
 // backward step KB of one strip: Z_KB = W_KB^T (V_KB - sum_j L[j][KB]^T Z_j); the finished block also goes to the
@@ -196,13 +210,12 @@ __device__ __forceinline__ void gf_fwd_strip(int c, const double* pa, int PA, in
 template <int KB, int NBT, bool SB>
 __device__ __forceinline__ void gf_bwd_strip(int last, const double* pb, double* zout, int lane) {
   using Dst = GfTile<gf_slot<NBT, SB>(KB)>;
+  GfOps cur = gf_load_ops(pb + 16 * (last > KB ? last : KB) * 16, 64);
   GF_DRAIN();
   Dst::copy_to_acc();   // V_KB: written by the forward pass, many steps (and barriers) ago
-  gf_bwd_chain<KB, NBT, SB>(last, pb);
-  const double* q = pb + 16 * KB * 16;
-  const double w0 = q[0], w1 = q[64], w2 = q[128], w3 = q[192];
+  gf_bwd_chain<KB, NBT, SB>(cur, last, pb);
   GF_DRAIN();
-  Dst::set_prod_acc(w0, w1, w2, w3);
+  Dst::set_prod_acc(cur.a0, cur.a1, cur.a2, cur.a3);
   GF_DRAIN();
   const d4_t z = Dst::get();
   zout[lane] = z[0]; zout[64 + lane] = z[1]; zout[128 + lane] = z[2]; zout[192 + lane] = z[3];
@@ -491,6 +504,20 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
   double g_os = 0.0, g_noise = 0.0, pd0 = 0.0, pd1 = 0.0;
   double* zs = zs_all + wave * 512;
 
+  // (-DGF_STAGGER: the second half of the waves defers a step's epilogue to the start of the next step, so that of
+  //  the two waves of a SIMD one streams MFMAs while its partner evaluates kernel functions -- measured SLOWER,
+  //  133.5 vs 127.3 us at T = 256, N = 256 in interleaved A/B runs: off)
+#ifdef GF_STAGGER
+  const bool late = NW >= 2 && wave >= NW / 2;
+#else
+  const bool late = false;
+#endif
+  auto epilogue = [&](int kb) {
+#ifndef GF_NO_EPI
+    if (kb >= cA) gf_epilogue<KIND>(stA, zs + lane, kb, cA, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
+    if (kb >= cB) gf_epilogue<KIND>(stB, zs + 256 + lane, kb, cB, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
+#endif
+  };
   for (int t = 0; t < 2 * NB; ++t) {
 #ifndef GF_NO_STAGE
     if constexpr (DMA) {
@@ -504,6 +531,7 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
 #endif
     const bool fwd = t < NB;
     const int kb = fwd ? t : 2 * NB - 1 - t;
+    if (late && t > NB) epilogue(kb + 1);    // the previous (backward) step's blocks
     const double* b = buf + (t & 1) * BUF;
     const double* pa = b + lc * PA + lq;     // forward A operand:  L[16 kb + lc][16 j + lq + 4 m]
     const double* pb = b + lq * 16 + lc;     // backward A operand: L[16 j + lq + 4 m][16 kb + lc]
@@ -513,15 +541,11 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
       GF_STEP_CASE(14) GF_STEP_CASE(15)
       default: break;
     }
-#ifndef GF_NO_EPI
-    if (!fwd) {
-      if (kb >= cA) gf_epilogue<KIND>(stA, zs + lane, kb, cA, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
-      if (kb >= cB) gf_epilogue<KIND>(stB, zs + 256 + lane, kb, cB, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
-    }
-#endif
+    if (!fwd && !late) epilogue(kb);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next slice have landed
     __syncthreads();
   }
+  if (late) epilogue(0);
 
   // ---- D + 2 sums: lengthscale partials over the 16 columns of a lane group (dimensions lq, lq + 4), the two scalars over
   // the wave; then over the waves in a fixed order; the task's totals go into tile slot 0
