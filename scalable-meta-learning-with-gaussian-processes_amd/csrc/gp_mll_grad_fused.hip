@@ -333,12 +333,17 @@ __device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int k
   }
 }
 
-template <int NBT, int KIND, bool DMA>
-__global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFusedParams p) {
+// SPLIT workgroups share a task (grid = (T, SPLIT)): the strips are independent, so each workgroup takes NW / SPLIT of
+// the NBT / 2 strip pairs, stages L for itself and writes its own partial sums (tile slot blockIdx.y).  Used when the
+// stack does not fill the CUs with one workgroup per task (BASELINE configs[3]: 128 tasks per GPU on 256 CUs).
+template <int NBT, int KIND, bool DMA, int SPLIT>
+__global__ __launch_bounds__(NBT * 32 / SPLIT) void gp_mll_grad_fused_kernel(MllGradFusedParams p) {
+  static_assert(SPLIT == 1 || (DMA && NBT >= 8 && (SPLIT == 2 || SPLIT == 4)), "split tasks: N <= 128 / N <= 256 classes with LDS-DMA staging only");
   constexpr int NP = 16 * NBT;
   constexpr int PA = NP + 2;             // pitch of a staged row block: lc * PA + lq hits 32 different 8-byte banks
-  constexpr int NW = NBT / 2;            // waves
-  constexpr int TPB = NBT * 32;
+  constexpr int NWT = NBT / 2;           // strip pairs = waves per task
+  constexpr int NW = NWT / SPLIT > 0 ? NWT / SPLIT : 1;   // waves of this workgroup
+  constexpr int TPB = NW * 64;
   constexpr int BUF = 16 * PA;           // doubles per staging buffer (a column block, NP x 16, fits as well)
   extern __shared__ double lds[];
   double* buf = lds;                     // [2][BUF]
@@ -363,7 +368,10 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
   const double os = th[D];
   // strip pair of this wave: (k, NBT-1-k); the second half of the waves takes the pairs in reverse, so that the two
   // waves of a SIMD (w, w + NW/2) carry pairs (s, NW-1-s) whose block counts per step add up evenly
-  const int kp = (NW < 2 || wave < NW / 2) ? wave : (NW + NW / 2 - 1 - wave);
+  // (split tasks: workgroup g of 2 takes the virtual waves {g, 3-g, 4+g, 7-g}, of 4 {g, g+4}: near-equal block counts again)
+  const int grp = SPLIT > 1 ? (int)blockIdx.y : 0;
+  const int vw = SPLIT == 1 ? wave : (SPLIT == 2 ? 2 * wave + ((wave & 1) ? 1 - grp : grp) : grp + 4 * wave);
+  const int kp = (NWT < 2 || vw < NWT / 2) ? vw : (NWT + NWT / 2 - 1 - vw);
   const int cA = kp, cB = NBT - 1 - kp;
 
   // ---- staging of one step's slice of L (t < NB: row block t, forward; else column block 2 NB - 1 - t, backward) with
@@ -565,20 +573,29 @@ __global__ __launch_bounds__(NBT * 32) void gp_mll_grad_fused_kernel(MllGradFuse
     const int src = tid < D ? tid : 8 + (tid - D);
     double s = 0.0;
     for (int w = 0; w < NW; ++w) s += red[w * 10 + src];
-    outp[tid] = s;
+    outp[grp * (D + 2) + tid] = s;
   }
-  for (int e = D + 2 + tid; e < NT * (D + 2); e += TPB) outp[e] = 0.0;
+  if (grp == 0)
+    for (int e = SPLIT * (D + 2) + tid; e < NT * (D + 2); e += TPB) outp[e] = 0.0;
 }
 #undef GF_STEP_CASE
 
 }  // namespace scaml
 
-#define SCAML_INSTANTIATE_GF(NBT)                                                                          \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, false>(scaml::MllGradFusedParams);     \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, false>(scaml::MllGradFusedParams);     \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, true>(scaml::MllGradFusedParams);      \
-  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, true>(scaml::MllGradFusedParams);
+#define SCAML_INSTANTIATE_GF(NBT)                                                                             \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, false, 1>(scaml::MllGradFusedParams);     \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, false, 1>(scaml::MllGradFusedParams);     \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 0, true, 1>(scaml::MllGradFusedParams);      \
+  template __global__ void scaml::gp_mll_grad_fused_kernel<NBT, 1, true, 1>(scaml::MllGradFusedParams);
 SCAML_INSTANTIATE_GF(2)
 SCAML_INSTANTIATE_GF(4)
 SCAML_INSTANTIATE_GF(8)
 SCAML_INSTANTIATE_GF(16)
+template __global__ void scaml::gp_mll_grad_fused_kernel<16, 0, true, 2>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<16, 1, true, 2>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<16, 0, true, 4>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<16, 1, true, 4>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<8, 0, true, 2>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<8, 1, true, 2>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<8, 0, true, 4>(scaml::MllGradFusedParams);
+template __global__ void scaml::gp_mll_grad_fused_kernel<8, 1, true, 4>(scaml::MllGradFusedParams);

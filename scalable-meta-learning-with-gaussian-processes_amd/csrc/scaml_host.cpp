@@ -23,6 +23,7 @@ extern "C" const unsigned long scaml_hsaco_blob_len;
 namespace {
 
 thread_local char g_last_error[256] = "";
+bool g_no_grad_split = getenv("SCAML_GRAD_NO_SPLIT") != nullptr;              // developer A/B switch
 bool g_force_two_launch_grad = getenv("SCAML_GRAD_LEGACY") != nullptr;   // developer A/B switch (scaml_debug_force_two_launch_grad)
 
 void set_error(const char* what, hipError_t e) {
@@ -52,6 +53,7 @@ struct Module {
   hipFunction_t chosolve = nullptr;
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
+  hipFunction_t mllgrad_split[2][2][2] = {};   // LDS-DMA staging, [N <= 128 | N <= 256 class][2 | 4 workgroups per task][kind]
   hipError_t load() {
     std::lock_guard<std::mutex> lk(mu);
     if (loaded) return hipSuccess;
@@ -97,9 +99,19 @@ struct Module {
       for (int kind = 0; kind < 2; ++kind) {
         for (int dma = 0; dma < 2; ++dma) {
           char name[128];
-          snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dELb%dEEEvNS_18MllGradFusedParamsE", 2 << sc, kind, dma);
+          snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dELb%dELi1EEEvNS_18MllGradFusedParamsE", 2 << sc, kind, dma);
           if ((e = hipModuleGetFunction(&mllgrad_fused[sc][kind][dma], mod, name)) != hipSuccess) return e;
           if ((e = hipFuncSetAttribute((const void*)mllgrad_fused[sc][kind][dma], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+        }
+      }
+    }
+    for (int cls = 0; cls < 2; ++cls) {
+      for (int sp = 0; sp < 2; ++sp) {
+        for (int kind = 0; kind < 2; ++kind) {
+          char name[128];
+          snprintf(name, sizeof(name), "_ZN5scaml24gp_mll_grad_fused_kernelILi%dELi%dELb1ELi%dEEEvNS_18MllGradFusedParamsE", 8 << cls, kind, 2 << sp);
+          if ((e = hipModuleGetFunction(&mllgrad_split[cls][sp][kind], mod, name)) != hipSuccess) return e;
+          if ((e = hipFuncSetAttribute((const void*)mllgrad_split[cls][sp][kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
         }
       }
     }
@@ -440,7 +452,20 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
     // direct-to-LDS staging moves raw 16-byte pieces: only where no element needs masking and every row is 16-byte aligned
     const int dma = (n_points == nullptr && N % 16 == 0 && ((uintptr_t)L % 16) == 0 && ((uintptr_t)Linv_diag % 16) == 0) ? 1 : 0;
-    e = hipModuleLaunchKernel(m.mllgrad_fused[sc][kind][dma], (unsigned)T, 1, 1, (unsigned)nbt * 32, 1, 1, (unsigned)lds, (hipStream_t)stream,
+    // a stack that leaves CUs idle with one workgroup per task is split over 2 or 4 workgroups per task (strips are
+    // independent): BASELINE configs[3] runs 128 tasks per GPU on 256 CUs
+    if (m.num_cus == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.num_cus = cus;
+      if (m.num_cus <= 0) m.num_cus = 256;
+    }
+    int split = 1;
+    if (sc >= 2 && dma && !g_no_grad_split) {
+      if (4 * T <= m.num_cus) split = 4;
+      else if (2 * T <= m.num_cus) split = 2;
+    }
+    hipFunction_t fn = split == 1 ? m.mllgrad_fused[sc][kind][dma] : m.mllgrad_split[sc - 2][split == 2 ? 0 : 1][kind];
+    e = hipModuleLaunchKernel(fn, (unsigned)T, (unsigned)split, 1, (unsigned)(nbt * 32 / split), 1, 1, (unsigned)lds, (hipStream_t)stream,
                               nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad_fused)", e); return SCAML_E_LAUNCH; }
     return SCAML_OK;
