@@ -33,11 +33,12 @@ def main():
     if "--json" in sys.argv:
         path = sys.argv[sys.argv.index("--json") + 1]
         if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
-            rec = dict(hbm_bytes_per_launch=(out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, fetch_size_kb=out["FETCH_SIZE"],
-                       write_size_kb=out["WRITE_SIZE"],
+            # gfx950: FETCH_SIZE reports half the bytes read (MI355X_MICROARCH.md; confirmed for 8- and 16-byte per-lane
+            # streams by tools/fetch_calib.hip, profiles/r02_fetch_write_size_calibration.txt); WRITE_SIZE is exact
+            rec = dict(hbm_bytes_per_launch=(2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, fetch_size_kb_raw=out["FETCH_SIZE"],
+                       fetch_size_kb_corrected=2.0 * out["FETCH_SIZE"], write_size_kb=out["WRITE_SIZE"],
                        note="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), median per dispatch of "
-                            f"{needle}, bench.py --steps 20 --warmup 2; FETCH_SIZE raw (the guide's x2 correction is "
-                            "calibrated for 16-B/lane streams; these reads are 8-B/lane)", round=1)
+                            f"{needle}; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B)")
             with open(path, "w") as fh:
                 json.dump(rec, fh, indent=1)
 
