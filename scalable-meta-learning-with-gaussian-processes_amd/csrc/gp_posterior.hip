@@ -303,6 +303,58 @@ extern "C" __global__ void scaml_weighted_task_sum_kernel(const double* __restri
   out[e] = s;
 }
 
+// ---- target GP (scamlgp/model.py:359-384 eval branch + gpytorch's exact prediction) ------------------
+// (1) assemble: the standardised joint prior of the target GP over cat(train_X (n), Xq (M)) from the weighted source
+// sums: K[i][c] = cov_s[i][c] / s^2 + os_t k_t(x_i, x_c) for the n training rows i and all n + M columns c -- the n x n
+// block (+ noise on its diagonal) goes to Knn, the cross block to Knq; resid = y~ - (mean_s - m) / s on the training
+// points, mean_q / var_q the standardised prior mean and variance (+ os_t) at the queries.  One element per thread.
+template <int KIND>
+__global__ void scaml_target_assemble_kernel(scaml::TargetAssembleParams p) {
+  __shared__ double exptab[64];
+  scaml::exp2_table_init(exptab, threadIdx.x);
+  __syncthreads();
+  const int n = p.n, M = p.M, D = p.D, W = n + M;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double s2 = p.s_all * p.s_all;
+  const double os = p.theta[D], noise = p.theta[D + 1];
+  if (e < (long long)n * W) {
+    const int i = (int)(e / W), c = (int)(e - (long long)i * W);
+    double d2 = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double df = (p.Xall[(size_t)i * D + d] - p.Xall[(size_t)c * D + d]) / p.theta[d];
+      d2 = __builtin_fma(df, df, d2);
+    }
+    const double v = p.cov_s[e] / s2 + os * scaml::kernel_from_sqdist<KIND>(d2, exptab);
+    if (c < n) p.Knn[(size_t)i * n + c] = v + (i == c ? noise : 0.0);
+    else p.Knq[(size_t)i * M + (c - n)] = v;
+  }
+  if (e < n) p.resid[e] = p.train_targets[e] - (p.mean_s[e] - p.m_all) / p.s_all;
+  if (e < M) {
+    p.mean_q[e] = (p.mean_s[n + e] - p.m_all) / p.s_all;
+    p.var_q[e] = p.var_s[n + e] / s2 + os;
+  }
+}
+template __global__ void scaml_target_assemble_kernel<0>(scaml::TargetAssembleParams);
+template __global__ void scaml_target_assemble_kernel<1>(scaml::TargetAssembleParams);
+
+// (2) finish: mu*_q = mean_q + Knq[:, q] . alpha, var*_q = var_q - Knq[:, q] . Z[:, q] with alpha = Knn^-1 resid and
+// Z = Knn^-1 Knq from the batched Cholesky / solve kernels (T = 1), un-standardised: m + s mu*, s^2 (var* + noise_add).
+extern "C" __global__ void scaml_target_finish_kernel(const double* __restrict__ Knq, const double* __restrict__ Z,
+                                                      const double* __restrict__ alpha, const double* __restrict__ mean_q,
+                                                      const double* __restrict__ var_q, double m_all, double s_all,
+                                                      double noise_add, int n, int M, double* __restrict__ mu, double* __restrict__ var) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  double a = mean_q[q], v = var_q[q];
+  for (int i = 0; i < n; ++i) {
+    const double k = Knq[(size_t)i * M + q];
+    a = __builtin_fma(k, alpha[i], a);
+    v = __builtin_fma(-k, Z[(size_t)i * M + q], v);
+  }
+  mu[q] = __builtin_fma(s_all, a, m_all);
+  var[q] = s_all * s_all * (v + noise_add);
+}
+
 template __global__ void scaml::gp_posterior_kernel<0>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_kernel<1>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_cov_kernel<0>(scaml::PosteriorCovParams);

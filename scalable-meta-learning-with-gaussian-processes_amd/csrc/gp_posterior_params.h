@@ -70,6 +70,22 @@ struct MllGradParams {
   int T, N, D;
 };
 
+struct TargetAssembleParams {
+  const double* cov_s;          // (n, n + M) weighted source covariance block, original units
+  const double* mean_s;         // (n + M)   weighted source mean
+  const double* var_s;          // (n + M)   weighted source variances (only [n:] is read)
+  const double* Xall;           // (n + M, D) target training inputs, then the query points
+  const double* theta;          // (D + 2) target kernel: lengthscales, outputscale, noise
+  const double* train_targets;  // (n) standardised target observations
+  double m_all, s_all;
+  double* Knn;                  // (n, n)
+  double* resid;                // (n)
+  double* Knq;                  // (n, M)
+  double* mean_q;               // (M)
+  double* var_q;                // (M)
+  int n, M, D;
+};
+
 struct MllGradFusedParams {
   const double* X;          // (T, N, D)
   const double* theta;      // (T, D+2)

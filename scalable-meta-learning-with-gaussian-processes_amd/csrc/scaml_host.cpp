@@ -52,6 +52,8 @@ struct Module {
   hipFunction_t kmat[2] = {nullptr, nullptr};
   hipFunction_t chosolve = nullptr;
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
+  hipFunction_t tgt_assemble[2] = {nullptr, nullptr};
+  hipFunction_t tgt_finish = nullptr;
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
   hipFunction_t mllgrad_split[2][2][2] = {};   // LDS-DMA staging, [N <= 128 | N <= 256 class][2 | 4 workgroups per task][kind]
   hipError_t load() {
@@ -105,6 +107,12 @@ struct Module {
         }
       }
     }
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      snprintf(name, sizeof(name), "_Z28scaml_target_assemble_kernelILi%dEEvN5scaml20TargetAssembleParamsE", kind);
+      if ((e = hipModuleGetFunction(&tgt_assemble[kind], mod, name)) != hipSuccess) return e;
+    }
+    if ((e = hipModuleGetFunction(&tgt_finish, mod, "scaml_target_finish_kernel")) != hipSuccess) return e;
     for (int cls = 0; cls < 2; ++cls) {
       for (int sp = 0; sp < 2; ++sp) {
         for (int kind = 0; kind < 2; ++kind) {
@@ -485,6 +493,43 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
                               nullptr, config);
     if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_mll_grad)", e); return SCAML_E_LAUNCH; }
   }
+  return SCAML_OK;
+}
+
+// ---- target GP: assemble the joint prior block / finish the posterior (a10) -----------------------------------------
+int scaml_target_assemble_f64(const double* cov_s, const double* mean_s, const double* var_s, const double* Xall,
+                              const double* theta, const double* train_targets, double m_all, double s_all, int n, int M, int D,
+                              int kind, double* Knn, double* resid, double* Knq, double* mean_q, double* var_q, void* stream) {
+  if (n < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
+  if (!cov_s || !mean_s || !var_s || !Xall || !theta || !train_targets || !Knn || !resid) return SCAML_E_BADARG;
+  if (M > 0 && (!Knq || !mean_q || !var_q)) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (!(s_all > 0.0)) return SCAML_E_BADARG;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  scaml::TargetAssembleParams p{cov_s, mean_s, var_s, Xall, theta, train_targets, m_all, s_all, Knn, resid, Knq, mean_q, var_q, n, M, D};
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  long long elems = (long long)n * (n + M);
+  if (elems < M) elems = M;
+  e = hipModuleLaunchKernel(m.tgt_assemble[kind], (unsigned)((elems + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_assemble)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+int scaml_target_finish_f64(const double* Knq, const double* Z, const double* alpha, const double* mean_q, const double* var_q,
+                            double m_all, double s_all, double noise_add, int n, int M, double* mu, double* var, void* stream) {
+  if (n < 1 || M < 0) return SCAML_E_BADARG;
+  if (M == 0) return SCAML_OK;
+  if (!Knq || !Z || !alpha || !mean_q || !var_q || !mu || !var) return SCAML_E_BADARG;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  void* args[] = {(void*)&Knq, (void*)&Z, (void*)&alpha, (void*)&mean_q, (void*)&var_q, (void*)&m_all, (void*)&s_all, (void*)&noise_add,
+                  (void*)&n, (void*)&M, (void*)&mu, (void*)&var};
+  e = hipModuleLaunchKernel(m.tgt_finish, (unsigned)((M + 127) / 128), 1, 1, 128, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_finish)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
 

@@ -472,6 +472,7 @@ class ScaMLGP:
         else:   # the same statistics from all-reduced sums: no rank ever holds the other shards' observations
             m, s = sdist.standardize_fit_sharded(self._stack.raw_targets(), self.train_Y, self._shard)
         self.m_all, self.s_all = (m.squeeze(), s.squeeze()) if self.has_transform else (self.train_Y.new_zeros(()), self.train_Y.new_ones(()))
+        self._m_all_f, self._s_all_f = float(self.m_all), float(self.s_all)   # (one sync here instead of one per posterior call)
         self.outcome_transform = _OutcomeTransform(self.m_all, self.s_all) if self.has_transform else None
         self.train_inputs = (self.train_X,)
         self.train_targets = ((self.train_Y - self.m_all) / self.s_all).squeeze(-1)
@@ -613,20 +614,33 @@ class ScaMLGP:
         launch with the full query block and is only computed when read."""
         Xq = torch.as_tensor(X, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device)
         n = self.n
-        mean, cov, var_q, theta = self._joint(Xq, full=False)
-        if n == 0:
-            mu, var = mean, var_q
+        if 1 <= n <= ops.fit_max_n():
+            # the library's target-GP path: weighted source sums at cat(train_X, Xq), then assemble -> jittered Cholesky
+            # (T = 1) -> solve -> finish: four launches, no host synchronisation, no torch arithmetic
+            xall = torch.cat([self.train_X, Xq], 0)
+            mu_s, cov_s, var_s = self._source_prior(xall, n)
+            mu_o, var_o, info, _ = ops.target_posterior(cov_s, mu_s, var_s, xall, self.theta, self.train_targets, self._m_all_f,
+                                                         self._s_all_f, self.kind, observation_noise)
+            # a factorisation that fails even with jitter (psd_safe_cholesky would raise NotPSDError) shows as NaN here:
+            # the status stays on the device so that an acquisition-function evaluation never waits for the host
+            bad = torch.where(info > 0, float("nan"), 0.0).to(torch.float64)   # (1,): NaN marks a failed factorisation
+            mu_o, var_o = mu_o + bad, var_o + bad
         else:
-            Knn = cov[:, :n] + theta[-1] * torch.eye(n, dtype=torch.float64, device=self.device)
-            Knq = cov[:, n:]
-            Lc = psd_safe_cholesky(Knn)
-            resid = (self.train_targets - mean[:n]).unsqueeze(-1)
-            a = torch.cholesky_solve(resid, Lc).squeeze(-1)
-            mu = mean[n:] + Knq.transpose(0, 1) @ a
-            Vq = torch.linalg.solve_triangular(Lc, Knq, upper=False)
-            var = var_q - (Vq * Vq).sum(0)
-        if observation_noise:
-            var = var + theta[-1]
+            mean, cov, var_q, theta = self._joint(Xq, full=False)
+            if n == 0:
+                mu, var = mean, var_q
+            else:
+                Knn = cov[:, :n] + theta[-1] * torch.eye(n, dtype=torch.float64, device=self.device)
+                Knq = cov[:, n:]
+                Lc = psd_safe_cholesky(Knn)
+                resid = (self.train_targets - mean[:n]).unsqueeze(-1)
+                a = torch.cholesky_solve(resid, Lc).squeeze(-1)
+                mu = mean[n:] + Knq.transpose(0, 1) @ a
+                Vq = torch.linalg.solve_triangular(Lc, Knq, upper=False)
+                var = var_q - (Vq * Vq).sum(0)
+            if observation_noise:
+                var = var + theta[-1]
+            mu_o, var_o = self.m_all + self.s_all * mu, self.s_all ** 2 * var
 
         def full_cov() -> torch.Tensor:
             _, cj, _, th = self._joint(Xq, full=True)
@@ -639,4 +653,4 @@ class ScaMLGP:
                 S = S + th[-1] * torch.eye(S.shape[0], dtype=torch.float64, device=self.device)
             return self.s_all ** 2 * S
 
-        return TargetPosterior(self.m_all + self.s_all * mu, self.s_all ** 2 * var, full_cov)
+        return TargetPosterior(mu_o, var_o, full_cov)

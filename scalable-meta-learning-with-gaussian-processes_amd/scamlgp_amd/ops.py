@@ -398,6 +398,42 @@ def weighted_prior_reduce(mu: Optional[torch.Tensor], cov: Optional[torch.Tensor
     return mu_s, cov_s
 
 
+def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Tensor, Xall: torch.Tensor, theta: torch.Tensor,
+                     train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False):
+    """Posterior mean / variance (original units) of the ScaML-GP target GP at the M query points behind the n training
+    points in ``Xall`` (n + M, D), from the weighted source sums at the same points: cov_s (n, n + M), mean_s, var_s
+    (n + M).  scaml_target_assemble_f64 -> scaml_potrf_batched_f64 (T = 1, jitter ladder) -> scaml_cho_solve_batched_f64
+    -> scaml_target_finish_f64: four launches, no host synchronisation.  Returns (mu (M,), var (M,), info (1,), jitter (1,))."""
+    n = int(train_targets.shape[0])
+    W, D = Xall.shape
+    M = W - n
+    if not 1 <= n <= _lib.lib.scaml_fit_max_n():
+        raise ValueError(f"target_posterior takes 1 <= n <= {_lib.lib.scaml_fit_max_n()} training points")
+    cov_s = _check(cov_s, "cov_s", (n, W))
+    mean_s = _check(mean_s, "mean_s", (W,))
+    var_s = _check(var_s, "var_s", (W,))
+    Xall = _check(Xall, "Xall")
+    theta = _check(theta, "theta", (D + 2,))
+    train_targets = _check(train_targets, "train_targets", (n,))
+    dev = Xall.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        Knn, resid = torch.empty((1, n, n), **f64), torch.empty((1, n), **f64)
+        Knq, mean_q, var_q = torch.empty((1, n, M), **f64), torch.empty((M,), **f64), torch.empty((M,), **f64)
+        rc = _lib.lib.scaml_target_assemble_f64(_ptr(cov_s), _ptr(mean_s), _ptr(var_s), _ptr(Xall), _ptr(theta), _ptr(train_targets),
+                                                float(m_all), float(s_all), n, M, D, int(kind), _ptr(Knn), _ptr(resid), _ptr(Knq),
+                                                _ptr(mean_q), _ptr(var_q), _stream_handle())
+        _lib.check_rc(rc, "scaml_target_assemble_f64")
+        f = potrf_batched(Knn, resid, want_linv=True)
+        mu, var = torch.empty((M,), **f64), torch.empty((M,), **f64)
+        if M > 0:
+            Z = cho_solve(f["L"], f["Linv_diag"], Knq)
+            rc = _lib.lib.scaml_target_finish_f64(_ptr(Knq), _ptr(Z), _ptr(f["alpha"]), _ptr(mean_q), _ptr(var_q), float(m_all), float(s_all),
+                                                  float(theta[D + 1]) if observation_noise else 0.0, n, M, _ptr(mu), _ptr(var), _stream_handle())
+            _lib.check_rc(rc, "scaml_target_finish_f64")
+    return mu, var, f["info"], f["jitter"]
+
+
 def mll_backward_workspace(T: int, N: int, D: int, device) -> Dict[str, torch.Tensor]:
     """Reusable buffers of ``mll_backward`` for a (T, N, D) stack: the explicit inverse factors (T N^2 doubles) and
     the per-tile partial sums.  An optimiser loop allocates them once (scaml_mll_backward_workspace_doubles)."""
