@@ -191,6 +191,17 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
                            double* workspace, double* partials_out, void* stream);
 
 /*
+ * (5c') The covariance block of (5b) fused into the posterior pass of (5c): with VA = V[:, :Ma] (T, N, Ma) -- the V of the
+ * first Ma query points, produced by a call of scaml_posterior_linv_f64 on those points alone -- one pass over all M
+ * query points gives mu, var AND cov (T, Ma, M) = s_t^2 (os k(xq_a, xq_c) - VA^T V); V (T, N, M) itself never reaches
+ * memory (at BASELINE configs[4]: 145 MB not written and not re-read per acquisition-function evaluation).  Replaces the
+ * same reference sites as (5) / (5b): scamlgp/model.py:128-134, 281-289.  Ma <= 96, Ma <= N, Ma <= M.
+ */
+int scaml_posterior_linv_cov_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                                 const double* y_mean, const double* y_std, const int32_t* n_points, const double* VA, int T, int N,
+                                 int M, int Ma, int D, int kind, double* mu, double* var, double* cov, unsigned flags, void* stream);
+
+/*
  * (7) Target GP posterior on top of the weighted source prior (scamlgp/model.py:359-384 eval branch, then gpytorch's
  * exact prediction: botorch GPyTorchModel.posterior -> ExactGP.__call__ in eval mode).
  * The reference evaluates it per acquisition-function call with ~40 small torch ops; here it is four launches and no

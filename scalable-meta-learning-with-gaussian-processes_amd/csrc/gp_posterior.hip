@@ -213,9 +213,15 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   __syncthreads();
 
   // ---- phase 2: V = L^-1 K_*^T by row blocks, the variance on the fly
+  constexpr int MAXAS = 6;   // fused covariance block: at most 96 leading query points (the target's training points)
+  const int nas = p.VA ? (p.Ma + 15) / 16 : 0;
+  d4_t cacc[MAXAS];
+#pragma unroll
+  for (int as = 0; as < MAXAS; ++as) cacc[as] = d4_t{0.0, 0.0, 0.0, 0.0};
   if (!p.mean_only) {
     double var_part = 0.0;
     const bool n_even = (N & 1) == 0;
+    const double* VAg = p.VA ? p.VA + (size_t)task * N * p.Ma : nullptr;
     for (int it = 0;; ++it) {
       const int kb = (it & 1) ? (it + 1) * 4 - 1 - wave : it * 4 + wave;
       if (kb >= NB) {
@@ -232,6 +238,26 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
         const int row = 16 * kb + lq + 4 * g;
         if (p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = row < n ? acc[g] : 0.0;
       }
+      if (nas) {
+        // cov tiles: (VA^T V)[a][c] += sum over the 16 rows of this block -- A = VA[rows][16 as + lc] transposed by the
+        // operand layout (A[i = lc][k = lq + 4 m] = VA[16 kb + lq + 4 m][16 as + lc]: 128-byte row segments), B = the
+        // V block just computed, straight from its accumulator registers (C/D layout = B-operand layout)
+        d4_t vb = acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vb[g] = (16 * kb + lq + 4 * g) < n ? vb[g] : 0.0;
+#pragma unroll
+        for (int as = 0; as < MAXAS; ++as) {
+          if (as < nas) {
+            const int ac = 16 * as + lc;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int row = 16 * kb + lq + 4 * m;
+              const double a = (row < n && ac < p.Ma) ? VAg[(size_t)row * p.Ma + ac] : 0.0;
+              cacc[as] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[m], cacc[as], 0, 0, 0);
+            }
+          }
+        }
+      }
     }
     var_part = sum_lane_groups(var_part);
     if (lq == 0) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(red + 16 + lc), var_part);
@@ -240,6 +266,44 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   if (tid < 16 && qc < M) {
     if (p.mu) p.mu[(size_t)task * M + qc] = __builtin_fma(ys, red[tid], ym);
     if (p.var) p.var[(size_t)task * M + qc] = ys * ys * (os - red[16 + tid]);
+  }
+  if (nas && !p.mean_only) {
+    // the four waves' partial tiles are added in a fixed order in the (now free) K_*^T strip, then
+    // cov[a][c] = s^2 (os k(xq_a, xq_c) - (VA^T V)[a][c]) for the Ma leading query points a and this strip's 16 points c
+    double* cb = Ks;   // [nas][256] register images; nas * 256 <= NP * 16 is checked by the host (Ma <= N)
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int as = 0; as < MAXAS; ++as) {
+          if (as < nas) {
+            d4_t v = cacc[as];
+            {   // gfx950: the last result pair of an fp64 MFMA is not interlocked for VALU / LDS reads -- settle first
+              asm volatile("s_nop 15\n\ts_nop 2" : "+v"(v));
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              double* dst = cb + as * 256 + g * 64 + lane;
+              *dst = (w == 0 ? 0.0 : *dst) + v[g];
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
+    for (int e = tid; e < nas * 256; e += blockDim.x) {
+      const int as = e >> 8, g = (e >> 6) & 3, ln = e & 63;
+      const int a = 16 * as + (ln >> 4) + 4 * g, c = ln & 15, qcc = 16 * strip + c;
+      if (a < p.Ma && qcc < M) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double df = Xqg[(size_t)a * D + d] * invl[d] - xqs[d * 16 + c];
+          d2 = __builtin_fma(df, df, d2);
+        }
+        const double kv = os * kernel_from_sqdist<KIND>(d2, exptab);
+        p.cov[((size_t)task * p.Ma + a) * M + qcc] = ys * ys * (kv - cb[e]);
+      }
+    }
   }
 }
 

@@ -21,6 +21,11 @@ struct PosteriorParams {
   int x_in_lds;
   int xq_per_task;  // Xq is (T, M, D) instead of (M, D)
   int mean_only;    // skip the triangular solve: only mu = m + s K_* alpha is produced
+  // fused covariance block (gp_posterior_linv_kernel only): with VA = V[:, :Ma] (T, N, Ma) of the first Ma query points given,
+  // cov (T, Ma, M) = s^2 (os k(xq_a, xq_c) - VA^T V) comes out of the same pass and V itself never reaches memory
+  const double* VA;
+  double* cov;
+  int Ma;
 };
 
 struct PosteriorCovParams {

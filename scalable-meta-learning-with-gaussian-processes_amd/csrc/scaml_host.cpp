@@ -399,14 +399,17 @@ int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32
   return launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
 }
 
-int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
-                             const double* y_mean, const double* y_std, const int32_t* n_points, int T, int N, int M, int D,
-                             int kind, double* mu, double* var, double* V, unsigned flags, void* stream) {
+static int posterior_linv_common(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                                 const double* y_mean, const double* y_std, const int32_t* n_points, const double* VA, int T, int N,
+                                 int M, int Ma, int D, int kind, double* mu, double* var, double* V, double* cov, unsigned flags,
+                                 void* stream) {
   if (T < 0 || N < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
   if (!Xq || !X || !theta || !Linv || !alpha) return SCAML_E_BADARG;
   if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
   if (flags & SCAML_POST_MEAN_ONLY) return SCAML_E_BADARG;   // (use scaml_posterior_batched_f64 for that)
   if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (VA && (!cov || Ma < 1 || Ma > M)) return SCAML_E_BADARG;
+  if (VA && (Ma > 96 || Ma > N)) return SCAML_E_TOOLARGE;      // six 16-point strips of leading query points at most
   if (T == 0 || M == 0) return SCAML_OK;
   Module& m = module();
   hipError_t e = m.load();
@@ -417,7 +420,7 @@ int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* th
   const bool xl = with_x <= 80 * 1024;   // keep at least two workgroups per CU
   if (base > 160 * 1024) return SCAML_E_TOOLARGE;
   scaml::PosteriorParams p{Xq, X, theta, Linv, nullptr, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0,
-                           (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0};
+                           (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0, VA, cov, VA ? Ma : 0};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const unsigned strips = (unsigned)((M + 15) / 16);
@@ -426,6 +429,21 @@ int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* th
                             nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
+}
+
+int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                             const double* y_mean, const double* y_std, const int32_t* n_points, int T, int N, int M, int D,
+                             int kind, double* mu, double* var, double* V, unsigned flags, void* stream) {
+  return posterior_linv_common(Xq, X, theta, Linv, alpha, y_mean, y_std, n_points, nullptr, T, N, M, 0, D, kind, mu, var, V, nullptr,
+                               flags, stream);
+}
+
+int scaml_posterior_linv_cov_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
+                                 const double* y_mean, const double* y_std, const int32_t* n_points, const double* VA, int T, int N,
+                                 int M, int Ma, int D, int kind, double* mu, double* var, double* cov, unsigned flags, void* stream) {
+  if (!VA || !cov) return SCAML_E_BADARG;
+  return posterior_linv_common(Xq, X, theta, Linv, alpha, y_mean, y_std, n_points, VA, T, N, M, Ma, D, kind, mu, var, nullptr, cov,
+                               flags, stream);
 }
 
 // ---- (4) gradient of the marginal log-likelihood ------------------------------------------------

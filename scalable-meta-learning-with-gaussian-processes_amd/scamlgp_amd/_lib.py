@@ -96,6 +96,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_mll_backward_workspace_doubles.argtypes = [c_int, c_int, c_int]
     lib.scaml_mll_backward_f64.restype = c_int
     lib.scaml_mll_backward_f64.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, _dp, _dp, c_void_p]
+    lib.scaml_posterior_linv_cov_f64.restype = c_int
+    lib.scaml_posterior_linv_cov_f64.argtypes = [_dp] * 9 + [c_int] * 6 + [_dp, _dp, _dp, ctypes.c_uint, c_void_p]
     c_double = ctypes.c_double
     lib.scaml_target_assemble_f64.restype = c_int
     lib.scaml_target_assemble_f64.argtypes = [_dp] * 6 + [c_double, c_double, c_int, c_int, c_int, c_int] + [_dp] * 5 + [c_void_p]
@@ -128,6 +130,7 @@ EXPORTED_SYMBOLS = (
     "scaml_weighted_prior_reduce_f64",
     "scaml_mll_backward_workspace_doubles",
     "scaml_mll_backward_f64",
+    "scaml_posterior_linv_cov_f64",
     "scaml_target_assemble_f64",
     "scaml_target_finish_f64",
 )

@@ -334,7 +334,28 @@ def source_posteriors(
     with torch.cuda.device(dev):
         mu = torch.empty((T, M), dtype=torch.float64, device=dev)
         var = torch.empty((T, M), dtype=torch.float64, device=dev) if want_var else None
-        V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if (cov_first > 0 or keep_V) else None
+        fused_cov = (Linv is not None and not mean_only and not keep_V and 0 < cov_first <= min(96, N, M))
+        V = torch.empty((T, N, M), dtype=torch.float64, device=dev) if ((cov_first > 0 and not fused_cov) or keep_V) else None
+        cov = None
+        if fused_cov:
+            # the covariance block comes out of the posterior pass itself: V of the leading cov_first points first
+            # (T, N, cov_first -- small), then one pass over all M points gives mean, var and cov; V (T, N, M) is never stored
+            Linv = _check(Linv, "Linv", (T, N, N))
+            Xa = Xq[:, :cov_first].contiguous() if Xq.dim() == 3 else Xq[:cov_first].contiguous()
+            VA = torch.empty((T, N, cov_first), dtype=torch.float64, device=dev)
+            mu_a = torch.empty((T, cov_first), dtype=torch.float64, device=dev)
+            rc = _lib.lib.scaml_posterior_linv_f64(
+                _ptr(Xa), _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean), _ptr(y_std), _ptr(n_points),
+                T, N, cov_first, D, int(kind), _ptr(mu_a), None, _ptr(VA), flags, _stream_handle())
+            _lib.check_rc(rc, "scaml_posterior_linv_f64")
+            cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)
+            if var is None:
+                var = torch.empty((T, M), dtype=torch.float64, device=dev)
+            rc = _lib.lib.scaml_posterior_linv_cov_f64(
+                _ptr(Xq), _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean), _ptr(y_std), _ptr(n_points), _ptr(VA),
+                T, N, M, cov_first, D, int(kind), _ptr(mu), _ptr(var), _ptr(cov), flags, _stream_handle())
+            _lib.check_rc(rc, "scaml_posterior_linv_cov_f64")
+            return dict(mean=mu, var=var if want_var else None, cov=cov, V=None)
         if Linv is not None and not mean_only:
             Linv = _check(Linv, "Linv", (T, N, N))
             rc = _lib.lib.scaml_posterior_linv_f64(
@@ -346,7 +367,6 @@ def source_posteriors(
             _ptr(Xq), _ptr(X), _ptr(theta), _ptr(L), _ptr(Linv_diag), _ptr(alpha), _ptr(y_mean), _ptr(y_std),
                 _ptr(n_points), T, N, M, D, int(kind), _ptr(mu), _ptr(var), _ptr(V), flags, _stream_handle())
             _lib.check_rc(rc, "scaml_posterior_batched_f64")
-        cov = None
         if cov_first > 0:
             cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)
             rc = _lib.lib.scaml_posterior_cov_f64(_ptr(Xq), _ptr(theta), _ptr(V), _ptr(y_std), T, N, M, cov_first, D,

@@ -150,3 +150,46 @@ def test_weighted_prior_reduce_matches_oracle(device):
     mu_only, none = ops.weighted_prior_reduce(mu.to(device), None, w.to(device))
     assert none is None
     torch.testing.assert_close(mu_only.cpu(), (w[:, None] * mu).sum(0), rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("T,N,D,M,Ma,kind,ragged,per_task", [
+    (3, 200, 4, 300, 80, O.KIND_MATERN52, False, False),   # the BO scoring shape: n = 80 training points in front of the candidates
+    (4, 96, 2, 40, 33, O.KIND_RBF, True, False),            # ragged stack, Ma not a multiple of 16
+    (2, 512, 6, 130, 96, O.KIND_MATERN52, False, False),    # N = 512 sources, the largest fused block (96 leading points)
+    (3, 64, 3, 50, 17, O.KIND_RBF, False, True),            # per-task query sets
+])
+def test_fused_covariance_block_matches_unfused_and_oracle(T, N, D, M, Ma, kind, ragged, per_task, device):
+    """scaml_posterior_linv_cov_f64 (the covariance block out of the posterior pass, V never stored) against the
+    V-in-memory path (scaml_posterior_linv_f64 + scaml_posterior_cov_f64) and, per task, against the oracle."""
+    d = synthetic.smooth_field_task_stack(T, N, D, seed=11 + N)
+    rng = np.random.default_rng(N + M)
+    npts = [N] * T
+    if ragged:
+        npts = [N, N - 37, 5, N - 1][:T]
+    ys = np.zeros((T, N))
+    ym, ysd = np.zeros(T), np.ones(T)
+    for t in range(T):
+        yy, mm, ss = synthetic.standardize_rows(d["Y"][t:t + 1, :npts[t]])
+        ys[t, :npts[t]], ym[t], ysd[t] = yy[0], mm[0], ss[0]
+    theta = torch.from_numpy(np.concatenate([0.5 * (1 + 0.4 * (rng.uniform(size=(T, D)) - 0.5)), np.ones((T, 1)), np.full((T, 1), 1e-3)], 1))
+    X, y = torch.from_numpy(d["X"]), torch.from_numpy(ys)
+    xq = torch.from_numpy(rng.uniform(size=(T, M, D) if per_task else (M, D)))
+    n_dev = torch.tensor(npts, dtype=torch.int32, device=device) if ragged else None
+    fit = _fit(X, y, theta, kind, device, n_dev)
+    Linv = ops.linv_batched(fit["L"], fit["Linv_diag"], n_points=n_dev)
+    args = (xq.to(device), X.to(device), theta.to(device), kind, None, None, fit["alpha"], torch.from_numpy(ym).to(device),
+            torch.from_numpy(ysd).to(device))
+    fused = ops.source_posteriors(*args, n_points=n_dev, cov_first=Ma, Linv=Linv)
+    assert fused["V"] is None
+    plain = ops.source_posteriors(*args, n_points=n_dev, cov_first=Ma, Linv=Linv, keep_V=True)   # keep_V: the V-in-memory path
+    scale = float(plain["cov"].abs().max())
+    torch.testing.assert_close(fused["mean"], plain["mean"], rtol=1e-12, atol=1e-13)
+    torch.testing.assert_close(fused["var"], plain["var"], rtol=1e-10, atol=1e-12 * scale)
+    torch.testing.assert_close(fused["cov"], plain["cov"], rtol=0, atol=1e-11 * scale)
+    for t in range(T):
+        n = npts[t]
+        ref = O.gp_fit(X[t, :n], y[t, :n], theta[t], kind)
+        xt = xq[t] if per_task else xq
+        mu, cov = O.source_posterior(xt, X[t, :n], theta[t], kind, ref["L"], ref["alpha"], float(ym[t]), float(ysd[t]))
+        torch.testing.assert_close(fused["mean"][t].cpu(), mu, rtol=RTOL, atol=RTOL * float(mu.abs().max()))
+        torch.testing.assert_close(fused["cov"][t].cpu(), cov[:Ma], rtol=0, atol=RTOL * float(cov.abs().max()))
