@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
 // ahead).  LDS is 37-53 KB per workgroup, so three to four of them share a CU and hide each other's
 // latencies -- the substitution kernel above holds a 32 KB strip per WAVE and runs one wave per SIMD.
 // XCD-aware block map (see gp_mll_grad_kernel): the strips of one task share an L2.
-template <int KIND>
+template <int KIND, bool COV>
 __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams p) {
   extern __shared__ double lds[];
   const int N = p.N, D = p.D, M = p.M;
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   __syncthreads();
 
   // ---- phase 2: V = L^-1 K_*^T by row blocks, the variance on the fly
-  constexpr int MAXAS = 6;   // fused covariance block: at most 96 leading query points (the target's training points)
-  const int nas = p.VA ? (p.Ma + 15) / 16 : 0;
+  // (COV: the variant with the fused covariance block -- ~90 more registers, so the plain pass keeps its own instantiation)
+  constexpr int MAXAS = COV ? 6 : 1;   // at most 96 leading query points (the target's training points)
+  const int nas = (COV && p.VA) ? (p.Ma + 15) / 16 : 0;
   d4_t cacc[MAXAS];
 #pragma unroll
   for (int as = 0; as < MAXAS; ++as) cacc[as] = d4_t{0.0, 0.0, 0.0, 0.0};
@@ -230,6 +231,19 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
       }
       const int arow = 16 * kb + lc;
       const double* Lrow = Li + (size_t)(arow < N ? arow : 0) * N;
+      // (fused covariance block: the VA operands of this row block are requested first and land under the products below)
+      double va[MAXAS][4];
+      if (nas) {
+#pragma unroll
+        for (int as = 0; as < MAXAS; ++as) {
+          const int ac = 16 * as + lc;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int row = 16 * kb + lq + 4 * m;
+            va[as][m] = (as < nas && row < n && ac < p.Ma) ? VAg[(size_t)row * p.Ma + ac] : 0.0;
+          }
+        }
+      }
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
       acc = block_row_accumulate<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
 #pragma unroll
@@ -248,13 +262,8 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
 #pragma unroll
         for (int as = 0; as < MAXAS; ++as) {
           if (as < nas) {
-            const int ac = 16 * as + lc;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-              const int row = 16 * kb + lq + 4 * m;
-              const double a = (row < n && ac < p.Ma) ? VAg[(size_t)row * p.Ma + ac] : 0.0;
-              cacc[as] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, vb[m], cacc[as], 0, 0, 0);
-            }
+            for (int m = 0; m < 4; ++m) cacc[as] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[as][m], vb[m], cacc[as], 0, 0, 0);
           }
         }
       }
@@ -450,5 +459,7 @@ __global__ void gp_kernel_matrix_kernel(scaml::KernelMatrixParams p) {
 }
 template __global__ void gp_kernel_matrix_kernel<0>(scaml::KernelMatrixParams);
 template __global__ void gp_kernel_matrix_kernel<1>(scaml::KernelMatrixParams);
-template __global__ void scaml::gp_posterior_linv_kernel<0>(scaml::PosteriorParams);
-template __global__ void scaml::gp_posterior_linv_kernel<1>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0, true>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1, true>(scaml::PosteriorParams);

@@ -47,6 +47,7 @@ struct Module {
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t post_linv[2] = {nullptr, nullptr};
+  hipFunction_t post_linv_cov[2] = {nullptr, nullptr};
   hipFunction_t wsum = nullptr;
   hipFunction_t linv = nullptr;
   hipFunction_t kmat[2] = {nullptr, nullptr};
@@ -79,9 +80,12 @@ struct Module {
       if ((e = hipFuncSetAttribute((const void*)post[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
       snprintf(name, sizeof(name), "_ZN5scaml23gp_posterior_cov_kernelILi%dEEEvNS_18PosteriorCovParamsE", kind);
       if ((e = hipModuleGetFunction(&post_cov[kind], mod, name)) != hipSuccess) return e;
-      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dEEEvNS_15PosteriorParamsE", kind);
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb0EEEvNS_15PosteriorParamsE", kind);
       if ((e = hipModuleGetFunction(&post_linv[kind], mod, name)) != hipSuccess) return e;
       if ((e = hipFuncSetAttribute((const void*)post_linv[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb1EEEvNS_15PosteriorParamsE", kind);
+      if ((e = hipModuleGetFunction(&post_linv_cov[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)post_linv_cov[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&linv, mod, "_ZN5scaml14gp_linv_kernelENS_10LinvParamsE")) != hipSuccess) return e;
@@ -425,7 +429,7 @@ static int posterior_linv_common(const double* Xq, const double* X, const double
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const unsigned strips = (unsigned)((M + 15) / 16);
   const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * strips;   // XCD-aware (task, strip) map inside the kernel
-  e = hipModuleLaunchKernel(m.post_linv[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
+  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
                             nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;

@@ -26,15 +26,47 @@ from .model import ScaMLGP, SourceGP
 from .utils import ExpectedImprovement, UpperConfidenceBound, optimize_marginal_likelihood
 
 
+class GraphedAcquisition:
+    """An acquisition function for ONE batch shape, captured once into a HIP graph and replayed per evaluation.
+
+    An evaluation of ``UpperConfidenceBound(model)(X)`` is ~15 launches of libscaml_hip.so (source posteriors with the
+    fused covariance block, the weighted task sums, the target GP's assemble / Cholesky / solve / finish) plus a few torch
+    element-wise kernels; at the batch sizes of the quasi-Newton phase (num_restarts x (2 dim + 1) points) the GPU work is
+    shorter than the Python time to enqueue it.  The library never synchronises and keeps every status on the device, so
+    the whole evaluation can be stream-captured: a replay is one host call.  The graph holds the ADDRESSES of the model's
+    parameter tensors: build a new one after the model is refitted (ScaMLGPBOLoop.suggest does, per BO step)."""
+
+    def __init__(self, af: Callable[[torch.Tensor], torch.Tensor], batch: int, dim: int, device: torch.device):
+        self.af, self.batch = af, batch
+        self.x = torch.zeros(batch, dim, dtype=torch.float64, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):          # warm-up off the default stream (allocator state, lazy module load)
+            for _ in range(2):
+                af(self.x)
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = af(self.x)
+
+    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+        if X.shape[0] != self.batch:
+            return self.af(X)
+        self.x.copy_(X, non_blocking=True)
+        self.graph.replay()
+        return self.out.clone()
+
+
 def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samples: int = 1024, num_restarts: int = 10,
                   max_iter: int = 50, generator: Optional[torch.Generator] = None, fd_step: float = 1e-4,
-                  eta: float = 2.0) -> Tuple[torch.Tensor, torch.Tensor]:
+                  eta: float = 2.0, graph_device: Optional[torch.device] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Maximise ``af`` over [0, 1]^dim; returns (x_best (dim,), af(x_best)).  botorch's ``optimize_acqf`` recipe:
     ``raw_samples`` random candidates -> ``num_restarts`` initial conditions (the best candidate plus a Boltzmann sample
     of the rest, ``initialize_q_batch``) -> ONE box-constrained L-BFGS-B run over all starts jointly (the summed
     acquisition value, which is separable over the starts: botorch's ``gen_candidates_scipy`` does the same) -> the
     best end point.  Every objective evaluation is one batched posterior call over the starts and their
-    central-difference stencils (one-sided at the box faces)."""
+    central-difference stencils (one-sided at the box faces).  With ``graph_device`` (the model's GPU) that evaluation
+    is captured into a HIP graph once and replayed per L-BFGS-B step (``GraphedAcquisition``)."""
     cand = torch.rand(raw_samples, dim, dtype=torch.float64, generator=generator)
     vals = af(cand).detach().cpu()
     R = min(num_restarts, raw_samples)
@@ -50,12 +82,13 @@ def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samp
     x0 = cand[picks]
     R = x0.shape[0]
     eye = torch.eye(dim, dtype=torch.float64)
+    af_step = GraphedAcquisition(af, R * (2 * dim + 1), dim, graph_device) if graph_device is not None else af
 
     def fun(zv: np.ndarray):
         x = torch.from_numpy(zv).reshape(R, dim)
         xp = (x.unsqueeze(1) + fd_step * eye).clamp(0.0, 1.0)      # (R, dim, dim): start r shifted along dimension d
         xm = (x.unsqueeze(1) - fd_step * eye).clamp(0.0, 1.0)
-        v = af(torch.cat([x, xp.reshape(-1, dim), xm.reshape(-1, dim)])).detach().cpu()
+        v = af_step(torch.cat([x, xp.reshape(-1, dim), xm.reshape(-1, dim)])).detach().cpu()
         dx = (xp - xm).diagonal(dim1=1, dim2=2)
         g = (v[R:R + R * dim].reshape(R, dim) - v[R + R * dim:].reshape(R, dim)) / dx
         f = float(v[:R].sum())
@@ -77,11 +110,12 @@ class ScaMLGPBOLoop:
     def __init__(self, source_gps: Dict[Hashable, SourceGP], dim: int, acquisition: str = "ucb", beta: float = 9.0,
                  num_restarts_log_likelihood: int = 5, raw_samples: int = 1024, num_restarts: int = 10, af_max_iter: int = 50,
                  gp_likelihood: Optional[hyper.GaussianLikelihood] = None, gp_kernel: Optional[hyper.ScaleKernel] = None,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, use_graph: bool = True):
         self.source_gps, self.dim = source_gps, dim
         self.acquisition, self.beta = acquisition, beta
         self.num_restarts_log_likelihood = num_restarts_log_likelihood
         self.raw_samples, self.num_restarts, self.af_max_iter = raw_samples, num_restarts, af_max_iter
+        self.use_graph = use_graph
         self.gen = torch.Generator().manual_seed(0 if seed is None else seed)
         self.X = torch.empty(0, dim, dtype=torch.float64)
         self.Y = torch.empty(0, 1, dtype=torch.float64)
@@ -110,7 +144,10 @@ class ScaMLGPBOLoop:
 
     def suggest(self) -> torch.Tensor:
         self.model.eval()
-        x, _ = optimize_acqf(self.acquisition_function(), self.dim, self.raw_samples, self.num_restarts, self.af_max_iter, self.gen)
+        # (the graph path needs training data on the model: the prior-only model takes the torch branch of posterior())
+        dev = self.model.device if (self.use_graph and self.model.n >= 1) else None
+        x, _ = optimize_acqf(self.acquisition_function(), self.dim, self.raw_samples, self.num_restarts, self.af_max_iter, self.gen,
+                             graph_device=dev)
         return x
 
     def run(self, objective: Callable[[torch.Tensor], float], n_steps: int):

@@ -457,6 +457,7 @@ class ScaMLGP:
         self.device = dev
         self.train_X = torch.as_tensor(train_X, dtype=torch.float64).reshape(-1, self._stack.D).to(dev)
         self.train_Y = torch.as_tensor(train_Y, dtype=torch.float64).reshape(-1, 1).to(dev)
+        self._idx_dev = torch.as_tensor(self._idx, dtype=torch.int64, device=dev)
         self._shard = self._stack.shard
         if self._shard is not None and len(gps) != self._stack.T:
             raise ValueError("a sharded source stack must be passed whole (every rank its full shard)")
@@ -541,11 +542,11 @@ class ScaMLGP:
         mask = significant_weights_mask(w, self._std_source_stds(), self._weight_pruning_threshold)
         if self._shard is not None:
             w, mask = w[self._shard.local], mask[self._shard.local]
-        idx = torch.as_tensor(self._idx, device=self.device)
-        w_full = torch.zeros(self._stack.T, dtype=torch.float64, device=self.device)
-        w_full[idx] = w
-        active = torch.zeros(self._stack.T, dtype=torch.bool, device=self.device)
-        active[idx[mask]] = True
+        # (scatter instead of mask indexing: nothing here depends on a value read back by the host, so the whole
+        #  acquisition pass can be captured into a HIP graph)
+        idx = self._idx_dev
+        w_full = torch.zeros(self._stack.T, dtype=torch.float64, device=self.device).scatter(0, idx, w)
+        active = torch.zeros(self._stack.T, dtype=torch.bool, device=self.device).scatter(0, idx, mask)
         return w_full, active
 
     def _source_prior(self, x: torch.Tensor, cov_first: int):

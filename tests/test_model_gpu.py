@@ -199,3 +199,21 @@ def test_meta_fit_large_source_tasks_hartmann6(device):
                                      float(stack.y_mean[t]), float(stack.y_std[t]))
         torch.testing.assert_close(post["mean"][t].cpu(), mu, rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(post["var"][t].cpu(), torch.diagonal(cov), rtol=1e-4, atol=1e-8)
+
+
+def test_graphed_acquisition_replays_match_eager(fitted, device):
+    """The acquisition pass captured into a HIP graph (bo.GraphedAcquisition) gives the eager values for new inputs,
+    replay after replay -- the library never synchronises, so the whole evaluation is stream-capturable."""
+    from scamlgp_amd.bo import GraphedAcquisition
+    meta, d, gps = fitted
+    g = torch.Generator().manual_seed(12)
+    Xt = torch.rand(6, 2, dtype=torch.float64, generator=g)
+    yt = torch.tensor(synthetic.branin(-5 + 15 * Xt[:, 0].numpy(), 15 * Xt[:, 1].numpy()), dtype=torch.float64).unsqueeze(-1)
+    model = M.ScaMLGP(Xt, yt, gps).eval()
+    model.weights = torch.tensor([0.4, 0.1, 0.3, 0.2], dtype=torch.float64)
+    for af in (utils.UpperConfidenceBound(model), utils.ExpectedImprovement(model, float(yt.min()))):
+        ga = GraphedAcquisition(af, 50, 2, device)
+        for _ in range(3):
+            X = torch.rand(50, 2, dtype=torch.float64, generator=g)
+            torch.testing.assert_close(ga(X), af(X), rtol=1e-12, atol=1e-14)
+        assert ga(X[:7]).shape == (7,)   # another batch size falls back to the eager path
