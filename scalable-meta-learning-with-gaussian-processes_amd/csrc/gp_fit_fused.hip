@@ -300,6 +300,19 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, d
                : "=&v"(out)                                                                        \
                : "v"(w0), "v"(w1), "v"(w2), "v"(w3))
 
+// out (VGPR tile) = tile^T-as-A-operand * W^T: the accumulator registers of the (transposed) tile are the A operand this
+// time (k-step m reads register pair m: A[i = lc][k = lq + 4m] = A_ik[lc][lq + 4m]), w0..w3 = W[lc][lq + 4m] the B operand
+// (= W^T[lq + 4m][lc]).  The result is the finalised tile UN-transposed (register g of lane (lc, lq) = L[lq + 4g][lc]):
+// the layout the finished tiles are kept in, straight off the matrix core -- no read-back through LDS.
+#define TILE_TRSM_ISSUE_UT(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, out)                    \
+  asm volatile("s_nop 1\n\t"                                                                     \
+               "v_mfma_f64_16x16x4_f64 %0, a[" #r0 ":" #r1 "], %1, 0\n\t"                         \
+               "v_mfma_f64_16x16x4_f64 %0, a[" #r2 ":" #r3 "], %2, %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, a[" #r4 ":" #r5 "], %3, %0\n\t"                        \
+               "v_mfma_f64_16x16x4_f64 %0, a[" #r6 ":" #r7 "], %4, %0"                             \
+               : "=&v"(out)                                                                        \
+               : "v"(w0), "v"(w1), "v"(w2), "v"(w3))
+
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 2" ::: "memory")
 
 // switch-dispatch of one runtime slot index onto the code for the matching physical tile
@@ -611,6 +624,35 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
 #endif
     constexpr int PSTORE = (WU == 7 && NB == 16) ? SCAML_PSTORE : 0;
 
+    // Forward substitution, by the panel wave alone: v_c = W_c y~_c, then column c (final in its LDS buffer) is folded into
+    // the running right-hand side, y~_i -= sum_q L[i][16 c + q] v_c[q] for the rows below block c.  v_c sits in SGPRs
+    // (the same 16 values for every lane), a lane owns whole rows: no atomics, no hand-off counter -- the update waves'
+    // F phase used to do this per tile (redundant v_c per wave, in-lane dot products + LDS atomics, a counter per
+    // column) on their critical path; the panel wave has the slack for it in the early panels, and the late columns are short.
+    auto fold_column = [&](int c) {
+      const double* Wc = WAll + c * 16 * PP;
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[(4 * lq + q) * PP + lc], ytil[16 * c + 4 * lq + q], v);
+      v = sum_lane_groups(v);
+      if (lq == 0) vv[16 * c + lc] = v;
+      if (16 * (c + 1) >= NP) return;
+      double vq[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) vq[q] = readlane_f64(v, q);
+      const double* col = PT + (c & 1) * PANEL;
+      for (int i = 16 * (c + 1) + lane; i < NP; i += 64) {
+        const double* row = col + i * PP;
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          s0 = __builtin_fma(row[q], vq[q], s0);
+          s1 = __builtin_fma(row[q + 1], vq[q + 1], s1);
+        }
+        ytil[i] -= s0 + s1;
+      }
+    };
+
     if (is_panel) {
       // ================= panel wave: the chain of diagonal blocks, running ahead of the update =========
       // (it is the youngest wave on its SIMD and would lose every issue slot to the update wave
@@ -648,6 +690,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           }
           for (; ti < NB; ++ti) store_tile(c, ti);
         }
+        if (j >= 2) fold_column(j - 2);   // (same window: column j-2 stays in its buffer until flagW[j] lets F(j) reuse it)
         d4_t a;
         {
           const double* dg = DG + (j & 1) * 256 + lane;   // symmetric: the transposed image is the block
@@ -695,6 +738,14 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             }
             r += WU;
           }
+        }
+      }
+      if (!flagp[0]) {
+        // the last two columns: column NB-2 once every update wave has finalised its tiles of it (nothing reuses its
+        // buffer any more), column NB-1 has no rows below it
+        if (sync_wait_ge_or_fail(cntT + NB - 2, WU, flagp)) {
+          fold_column(NB - 2);
+          fold_column(NB - 1);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -786,72 +837,41 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           for (int u = 0; u < MAXC; ++u) {
             const int s = sa + u;
             if (s < sb && c + (s * WU + wave - offc) != c) {
-#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_TRSM_ISSUE(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, t[u]);
+#define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_TRSM_ISSUE_UT(r0, r1, r2, r3, r4, r5, r6, r7, w0, w1, w2, w3, t[u]);
               SCAML_DISPATCH(s)
 #undef SCAML_BODY
             }
           }
-          if (sa < sb) {
-            // forward substitution rides along (in the shadow of the MFMAs just issued): v_c = W_c y_c,
-            // formed (redundantly, identical values) by every wave that holds a tile of column c; y_c is
-            // complete once column c-1 has been folded
-            if (c >= 1 && !sync_wait_ge_or_fail(cntY + c - 1, WU, flagp)) goto update_done;
-            double v = 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v = __builtin_fma(Wc[(4 * lq + q) * PP + lc], ytil[16 * c + 4 * lq + q], v);
-            v = sum_lane_groups(v);
-            if (lq == 0) vv[16 * c + lc] = v;
-            STAMP_K(k, 5);
-          }
           MFMA_DRAIN();
           STAMP_K(k, 7);
+          // The finished tiles come off the matrix core UN-transposed (lane (lc, lq) register g = L[16 ti + lq + 4 g][16 c + lc]):
+          // into the LDS column buffer for everyone's operand reads, and back into their accumulator registers as they
+          // are -- nothing updates them any more, and the back-substitution at the end contracts over rows, which this
+          // layout keeps inside a lane.  (The forward substitution -- v_c and the fold of column c into the running
+          // right-hand side -- is the panel wave's: fold_column.)
 #pragma unroll
           for (int u = 0; u < MAXC; ++u) {
             const int s = sa + u;
             const int ti = c + (s * WU + wave - offc);
             if (s < sb && ti != c) {
               asm volatile("" : "+v"(t[u]));   // the values exist only after the drain
-              // lane (lc, lq) register g holds L[16 ti + lc][16 c + lq + 4 g]
-              double* prow = cbuf + (16 * ti + lc) * PP + lq;
-              prow[0] = t[u][0]; prow[4] = t[u][1]; prow[8] = t[u][2]; prow[12] = t[u][3];
+              double* prow = cbuf + (16 * ti + lq) * PP + lc;
+              prow[0] = t[u][0]; prow[4 * PP] = t[u][1]; prow[8 * PP] = t[u][2]; prow[12 * PP] = t[u][3];
             }
           }
           sync_arrive(cntT + c, lane);
           STAMP_K(k, 8);
-          // running right-hand side: y_i -= L_ic v_c -- a row dot product per lane; the four lane groups
-          // add their parts with LDS fp64 atomics (each row of y has one owner tile per column)
-          {
-            const double* pv = vv + 16 * c + lq;
-            const double v0 = pv[0], v1 = pv[4], v2 = pv[8], v3 = pv[12];
-#pragma unroll
-            for (int u = 0; u < MAXC; ++u) {
-              const int s = sa + u;
-              const int ti = c + (s * WU + wave - offc);
-              if (s < sb && ti != c) {
-                double sdot = t[u][0] * v0;
-                sdot = __builtin_fma(t[u][1], v1, sdot);
-                sdot = __builtin_fma(t[u][2], v2, sdot);
-                sdot = __builtin_fma(t[u][3], v3, sdot);
-                __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(ytil + 16 * ti + lc), -sdot);
-              }
-            }
-          }
-          // The finished tiles go back into their registers UN-transposed (read back from the panel:
-          // lane (lc, lq) register g = L[16 ti + lq + 4 g][16 c + lc]): nothing updates them any more, and
-          // the back-substitution at the end contracts over rows, which this layout keeps inside a lane.
 #pragma unroll
           for (int u = 0; u < MAXC; ++u) {
             const int s = sa + u;
             const int ti = c + (s * WU + wave - offc);
             if (s < sb && ti != c) {
-              const double* prow = cbuf + (16 * ti + lq) * PP + lc;
-              const double e0 = prow[0], e1 = prow[4 * PP], e2 = prow[8 * PP], e3 = prow[12 * PP];
+              const double e0 = t[u][0], e1 = t[u][1], e2 = t[u][2], e3 = t[u][3];
 #define SCAML_BODY(r0, r1, r2, r3, r4, r5, r6, r7) TILE_SET(r0, r1, r2, r3, r4, r5, r6, r7, e0, e1, e2, e3);
               SCAML_DISPATCH(s)
 #undef SCAML_BODY
             }
           }
-          sync_arrive(cntY + c, lane);
           STAMP_K(k, 9);
           store_diag(c);
           STAMP_K(k, 10);
