@@ -59,6 +59,29 @@ def hartmann6(x, alpha=HARTMANN_ALPHA_DEFAULT):
     return hartmann(x, alpha, HARTMANN6_A, HARTMANN6_P)
 
 
+# --- Quadratic (functions/quadratic.py:10-31; family ranges benchmarks/quadratic.py:23-31) ------------------------------
+QUADRATIC_PARAM_RANGES = dict(a=(0.5, 1.5), b=(-0.9, 0.9), c=(-1.0, 1.0))
+QUADRATIC_BOUNDS = (-1.0, 1.0)
+
+
+def quadratic(x, a=1.0, b=0.0, c=0.0):
+    """f(x) = (a (x + b))^2 + c on x in [-1, 1]."""
+    return (np.asarray(a, dtype=np.float64) * (np.asarray(x, dtype=np.float64) + b)) ** 2 + c
+
+
+# --- designs ------------------------------------------------------------------------------------------------------
+def unit_cube_design(T: int, N: int, D: int, rng: np.random.Generator, design: str = "random") -> np.ndarray:
+    """(T, N, D) points in the unit cube: i.i.d. uniform ("random", benchmarks/base.py:119-150 samples the search space
+    at random) or one scrambled Sobol sequence per task ("sobol": the space-filling initial designs of the BO literature)."""
+    if design == "random":
+        return rng.uniform(size=(T, N, D))
+    if design == "sobol":
+        from scipy.stats import qmc
+
+        return np.stack([qmc.Sobol(d=D, scramble=True, seed=int(rng.integers(2 ** 31))).random(N) for _ in range(T)], 0)
+    raise ValueError(f"unknown design {design!r}")
+
+
 # --- task stacks ---------------------------------------------------------------------
 def standardize_rows(Y: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Per-task Standardize(m=1) (botorch semantics, scamlgp/model.py:185): unbiased std,
@@ -80,6 +103,27 @@ def branin_task_stack(T: int, N: int, seed: int = 0, noise_std: float = 1.0) -> 
     Y = branin(x1, x2, *(params[k][:, None] for k in ("a", "b", "c", "r", "s", "t")))
     Y = Y + noise_std * rng.standard_normal(Y.shape)
     return dict(X=X, Y=Y, params=np.stack([params[k] for k in ("a", "b", "c", "r", "s", "t")], 1))
+
+
+def quadratic_task_stack(T: int, N: int, seed: int = 0, noise_std: float = 0.0, design: str = "random") -> Dict[str, np.ndarray]:
+    """T tasks of the one-dimensional Quadratic family (benchmarks/quadratic.py:23-31), x in [-1, 1] mapped to [0, 1]."""
+    rng = np.random.default_rng(seed)
+    X = unit_cube_design(T, N, 1, rng, design)
+    params = {k: rng.uniform(lo, hi, size=T) for k, (lo, hi) in QUADRATIC_PARAM_RANGES.items()}
+    x = QUADRATIC_BOUNDS[0] + X[..., 0] * (QUADRATIC_BOUNDS[1] - QUADRATIC_BOUNDS[0])
+    Y = quadratic(x, params["a"][:, None], params["b"][:, None], params["c"][:, None])
+    Y = Y + noise_std * rng.standard_normal(Y.shape)
+    return dict(X=X, Y=Y, params=np.stack([params[k] for k in ("a", "b", "c")], 1))
+
+
+def hartmann3_task_stack(T: int, N: int, seed: int = 0, noise_std: float = 0.1, design: str = "random") -> Dict[str, np.ndarray]:
+    """T Hartmann-3 family tasks (alpha ranges benchmarks/hartmann_3d.py:31-34)."""
+    rng = np.random.default_rng(seed)
+    X = unit_cube_design(T, N, 3, rng, design)
+    alphas = np.stack([rng.uniform(lo, hi, size=T) for lo, hi in HARTMANN_ALPHA_RANGES], 1)
+    Y = np.stack([hartmann3(X[t], alphas[t]) for t in range(T)], 0)
+    Y = Y + noise_std * rng.standard_normal(Y.shape)
+    return dict(X=X, Y=Y, params=alphas)
 
 
 def hartmann6_task_stack(T: int, N: int, seed: int = 0, noise_std: float = 0.1) -> Dict[str, np.ndarray]:

@@ -43,3 +43,23 @@ def test_standardize_rows_matches_botorch_semantics():
     np.testing.assert_allclose(m, [7 / 3, 3.0])
     np.testing.assert_allclose(s, [np.std([1, 2, 4], ddof=1), 1.0])
     np.testing.assert_allclose(Ys[1], 0.0)
+
+
+def test_quadratic_family_and_hartmann3_stack_and_sobol_design():
+    # functions/quadratic.py:31: f = (a (x + b))^2 + c; minimum c at x = -b
+    assert float(S.quadratic(-0.3, a=1.2, b=0.3, c=-0.5)) == -0.5
+    np.testing.assert_allclose(S.quadratic(np.array([0.0, 1.0]), 2.0, 0.5, 1.0), [2.0, 10.0])
+    q = S.quadratic_task_stack(4, 16, seed=2)
+    assert q["X"].shape == (4, 16, 1) and q["params"].shape == (4, 3)
+    for k, (lo, hi) in enumerate(S.QUADRATIC_PARAM_RANGES.values()):
+        assert np.all((q["params"][:, k] >= lo) & (q["params"][:, k] <= hi))
+    x = -1.0 + 2.0 * q["X"][1, :, 0]
+    np.testing.assert_allclose(q["Y"][1], (q["params"][1, 0] * (x + q["params"][1, 1])) ** 2 + q["params"][1, 2])
+    h = S.hartmann3_task_stack(3, 8, seed=1, design="sobol")
+    assert h["X"].shape == (3, 8, 3) and h["params"].shape == (3, 4) and np.all((h["X"] >= 0) & (h["X"] < 1))
+    # a scrambled Sobol design is seeded and fills the cube more evenly than its size in random points would
+    a = S.unit_cube_design(1, 64, 2, np.random.default_rng(0), "sobol")
+    b = S.unit_cube_design(1, 64, 2, np.random.default_rng(0), "sobol")
+    np.testing.assert_array_equal(a, b)
+    counts = np.histogram2d(a[0, :, 0], a[0, :, 1], bins=4, range=[[0, 1], [0, 1]])[0]
+    assert counts.min() == counts.max() == 4   # 64 points: exactly 4 in each of the 16 cells
