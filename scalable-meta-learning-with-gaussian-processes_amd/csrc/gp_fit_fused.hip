@@ -338,29 +338,28 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   static_assert(SLOTS <= 20, "tile_regs.inc provides 20 accumulator tiles");
 
   extern __shared__ double lds[];
-  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[2][NP][PP] + WAll[NB][16][PP] +
+  // region A (overlaid): xsT [D][NP] during the kernel-matrix build; PT[3][NP][PP] (round 2: three column buffers) + WAll[NB][16][PP] +
   // DG[2][256] + CR[2][256] (parked diagonal / sub-diagonal tiles for the panel wave, register image) +
   // LT[2][16][PP] (factored diagonal blocks) afterwards
   double* xsT = lds;
   double* PT = lds;
-  double* WAll = lds + 2 * PANEL;
+  double* WAll = lds + 3 * PANEL;
   double* DG = WAll + NB * 16 * PP;
   double* CR = DG + 2 * 256;
   double* LT = CR + 2 * 256;
-  constexpr int REGION_A = 2 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
+  constexpr int REGION_A = 3 * PANEL + (NB + 2) * 16 * PP + 4 * 256;
   // (during the build: xsT, then up to 24 tile images written by the panel wave, see PANEL_BUILDS)
   const int XROWS = ((p.D + 3) & ~3) + 4;   // staged point stack: D rounded up to the MFMA k-step + 4 tail rows
   const int buildA = XROWS * NP + ((WU == 7 && NB == 16) ? 24 * 256 : 0);
   const int regionA = (buildA > REGION_A) ? buildA : REGION_A;
   double* ytil = lds + regionA;   // [NP] running right-hand side
   double* vv = ytil + NP;         // [NP] v = L^-1 y
-  double* ww = vv + NP;           // [NP] back-substitution workspace -> alpha
-  double* dl = ww + NP;           // [NP] diag(L)
+  double* ww = PT + 2 * PANEL;    // [NP] back-substitution workspace -> alpha: tail only, on the (then free) third column buffer
+  double* dl = vv + NP;           // [NP] diag(L)
   double* trash = dl + NP;        // [80] per-lane dump slots of the panel wave (lane + step) + [16] pivot log
   double* exptab = trash + 96;    // [64] 2^(j/64) for exp_neg
   int* rowlist = (int*)(exptab + 64);  // [WU][NB][8]: count, then up to 7 packed (slot << 8 | column) per block row
-  double* akscr = exptab + 64 + WU * NB * 4;  // [WU][16] alpha_k by wave (back-substitution)
-  double* invl = akscr + WU * 16;  // [D]  1 / lengthscale
+  double* invl = exptab + 64 + WU * NB * 4;  // [D]  1 / lengthscale
   int* flagp = (int*)(invl + p.D + (p.D & 1));  // [2] fail index
   int* flagW = flagp + 2;        // [NB] 1: W_k, v_k, L_kk published by the panel wave; 2: failed pivot
   int* cntT = flagW + NB;        // [NB] update waves done with T(k): column k final in LDS
@@ -596,7 +595,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     // 128-byte stores; the mirrored upper tile is written as zeros by the same lanes on request (no
     // separate zero-fill pass over L).
     auto store_tile = [&](int c, int ti) {
-      const double* prow = PT + (c & 1) * PANEL + (16 * ti + lq) * PP + lc;
+      const double* prow = PT + (c % 3) * PANEL + (16 * ti + lq) * PP + lc;
       const double e[4] = {prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]};
       double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c);   // tile (ti, c), wave-uniform
       double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti);   // mirrored tile (c, ti)
@@ -640,7 +639,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       double vq[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) vq[q] = readlane_f64(v, q);
-      const double* col = PT + (c & 1) * PANEL;
+      const double* col = PT + (c % 3) * PANEL;
       for (int i = 16 * (c + 1) + lane; i < NP; i += 64) {
         const double* row = col + i * PP;
         double s0 = 0.0, s1 = 0.0;
@@ -664,33 +663,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         // owners during U1(j-2): one whole step of slack, the chain does not wait in steady state
         if (j >= 2) sync_wait_ge(cntS + j - 2, WU);
         STAMP(3);
-        // (cntS[j-2] complete: column j-2 is final in its LDS buffer, which F(j) reuses after flagW[j])
-        if (Lg && j >= 2 && j - 2 < PSTORE) {
-          // (SCAML_STRIP tiles per trip: their LDS reads are issued together, one exposed latency for all)
-#ifndef SCAML_STRIP
-#define SCAML_STRIP 4
-#endif
-          const int c = j - 2;
-          int ti = j - 1;
-          for (; ti + SCAML_STRIP - 1 < NB && 16 * (ti + SCAML_STRIP) <= n; ti += SCAML_STRIP) {
-            const double* prow = PT + (c & 1) * PANEL + (16 * ti + lq) * PP + lc;
-            double e[4 * SCAML_STRIP];
-#pragma unroll
-            for (int u = 0; u < 4 * SCAML_STRIP; ++u) e[u] = prow[4 * u * PP];
-            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c) + lane_idx;
-#pragma unroll
-            for (int u = 0; u < 4 * SCAML_STRIP; ++u) tb[(size_t)4 * u * N] = e[u];
-            if (zero_upper) {
-              double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti) + lane_idx;
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int u = 0; u < SCAML_STRIP; ++u) mb[(size_t)g * 4 * N + 16 * u] = 0.0;
-            }
-          }
-          for (; ti < NB; ++ti) store_tile(c, ti);
-        }
-        if (j >= 2) fold_column(j - 2);   // (same window: column j-2 stays in its buffer until flagW[j] lets F(j) reuse it)
         d4_t a;
         {
           const double* dg = DG + (j & 1) * 256 + lane;   // symmetric: the transposed image is the block
@@ -721,6 +693,35 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
         sync_publish(flagW + j, 1, lane);
         STAMP_AT(j);
         STAMP(9);
+        // Column j-2 (final in its LDS buffer since cntS[j-2]) goes to HBM and into the running right-hand side AFTER
+        // flagW[j] is out: with three column buffers its buffer is not reused before F(j+1), i.e. before this wave has
+        // published flagW[j+1] -- the stores and the fold (3.3 k cycles per step) are off the path to flagW.
+        if (Lg && j >= 2 && j - 2 < PSTORE) {
+          // (SCAML_STRIP tiles per trip: their LDS reads are issued together, one exposed latency for all)
+#ifndef SCAML_STRIP
+#define SCAML_STRIP 4
+#endif
+          const int c = j - 2;
+          int ti = j - 1;
+          for (; ti + SCAML_STRIP - 1 < NB && 16 * (ti + SCAML_STRIP) <= n; ti += SCAML_STRIP) {
+            const double* prow = PT + (c % 3) * PANEL + (16 * ti + lq) * PP + lc;
+            double e[4 * SCAML_STRIP];
+#pragma unroll
+            for (int u = 0; u < 4 * SCAML_STRIP; ++u) e[u] = prow[4 * u * PP];
+            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c) + lane_idx;
+#pragma unroll
+            for (int u = 0; u < 4 * SCAML_STRIP; ++u) tb[(size_t)4 * u * N] = e[u];
+            if (zero_upper) {
+              double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti) + lane_idx;
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < SCAML_STRIP; ++u) mb[(size_t)g * 4 * N + 16 * u] = 0.0;
+            }
+          }
+          for (; ti < NB; ++ti) store_tile(c, ti);
+        }
+        if (j >= 2) fold_column(j - 2);
         if (j == 1 && lane < WU) {
           // Off the critical path (the chain waits for parked tiles next anyway): which off-diagonal tiles of
           // each block row the update waves hold, for the back-substitution at the end -- lane w lists wave w.
@@ -778,8 +779,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       // iteration k = -1 only finalises column 0
       for (int k = -1; k + 1 < NB; ++k) {
         const int c = k + 1;                          // the column finalised in this iteration
-        const double* buf = PT + (k & 1) * PANEL;     // column k, final (operand reads)
-        double* cbuf = PT + (c & 1) * PANEL;          // receives column c
+        const double* buf = PT + ((k + 3) % 3) * PANEL;     // column k, final (operand reads)
+        double* cbuf = PT + (c % 3) * PANEL;          // receives column c
         if (k >= 0) {
           // (every wait below gives up when the panel wave has reported a failed pivot: the waves it is
           //  waiting for may have left already)
@@ -818,6 +819,34 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           STAMP_AT(k);
           STAMP(4);
         }
+        if (k >= 0) {
+          // U2: the bulk of the trailing update with panel k: every slot from slo(k+2) on, entered through
+          // one switch and then falling through slot after slot (the parked D_{k+2} is skipped).
+          // Round 2: U2(k) runs BEFORE F(k+1) -- the time a wave used to spend in front of flagW[k+1] waiting for the
+          // panel wave (1.4-2.9 k cycles per iteration) is bulk work now; cntT[k+1] arrives later, but nobody needs it
+          // before his own U2(k) is through (109.2 -> 105 us in interleaved A/B; round 1 had F first).
+          const int s0 = slo(k + 2);
+          int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
+#define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
+          case S:                                                                                  \
+            if (S < SLOTS) {                                                                       \
+              while (uj < NB && ur >= NB - uj) { ur -= NB - uj; ++uj; }                            \
+              if (uj < NB) {                                                                       \
+                if (ur != 0 || uj != k + 2) {                                                      \
+                  const double* pj = buf + (16 * uj + lc) * PP + lq;                               \
+                  const double* pi = buf + (16 * (uj + ur) + lc) * PP + lq;                        \
+                  TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pj[0], pj[4], pj[8], pj[12], pi[0], pi[4], pi[8], pi[12]); \
+                }                                                                                  \
+                ur += WU;                                                                          \
+              }                                                                                    \
+            }
+          switch (s0) { SCAML_TILE_LIST(SCAML_U2_) default: break; }
+#undef SCAML_U2_
+          MFMA_DRAIN();
+          sync_arrive(cntU + k, lane);
+          STAMP_K(k, 11);
+          STAMP(7);
+        }
         // ---- F(c): column c becomes final
         {
           int fw;
@@ -827,8 +856,8 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           if (fw == 2) break;
           const double* Wc = WAll + c * 16 * PP;
           const int sa = slo(c), sb = slo(c + 1), offc = off(c);
-          // everyone must be done reading column c-2 (operands of U2(c-2)) before its buffer is reused
-          if (sa < sb && c >= 2 && !sync_wait_ge_or_fail(cntU + c - 2, WU, flagp)) goto update_done;
+          // everyone must be done reading column c-3 (operands of U2(c-3), its HBM stores) before its buffer -- one of three -- is reused
+          if (sa < sb && c >= 3 && !sync_wait_ge_or_fail(cntU + c - 3, WU, flagp)) goto update_done;
           STAMP_K(k, 6);
           const double* pw = Wc + lq * PP + lc;   // W[lc][lq + 4m] out of the transposed copy
           const double w0 = pw[0], w1 = pw[4 * PP], w2 = pw[8 * PP], w3 = pw[12 * PP];
@@ -876,31 +905,6 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           store_diag(c);
           STAMP_K(k, 10);
           STAMP(6);
-        }
-        if (k >= 0) {
-          // U2: the bulk of the trailing update with panel k: every slot from slo(k+2) on, entered through
-          // one switch and then falling through slot after slot (the parked D_{k+2} is skipped)
-          const int s0 = slo(k + 2);
-          int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
-#define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
-          case S:                                                                                  \
-            if (S < SLOTS) {                                                                       \
-              while (uj < NB && ur >= NB - uj) { ur -= NB - uj; ++uj; }                            \
-              if (uj < NB) {                                                                       \
-                if (ur != 0 || uj != k + 2) {                                                      \
-                  const double* pj = buf + (16 * uj + lc) * PP + lq;                               \
-                  const double* pi = buf + (16 * (uj + ur) + lc) * PP + lq;                        \
-                  TILE_MFMA4_SUB(r0, r1, r2, r3, r4, r5, r6, r7, pj[0], pj[4], pj[8], pj[12], pi[0], pi[4], pi[8], pi[12]); \
-                }                                                                                  \
-                ur += WU;                                                                          \
-              }                                                                                    \
-            }
-          switch (s0) { SCAML_TILE_LIST(SCAML_U2_) default: break; }
-#undef SCAML_U2_
-          MFMA_DRAIN();
-          sync_arrive(cntU + k, lane);
-          STAMP_K(k, 11);
-          STAMP(7);
         }
         store_column(c);
         STAMP_K(k, 12);

@@ -149,11 +149,11 @@ Module& module() {
 
 size_t fit_lds_bytes(int nb, int wu, int D) {
   const int np = nb * 16;
-  size_t regionA = (size_t)2 * np * PP + (size_t)(nb + 2) * 16 * PP + 4 * 256;   // PT[2], WAll[nb], LT[2], DG[2], CR[2]
+  size_t regionA = (size_t)3 * np * PP + (size_t)(nb + 2) * 16 * PP + 4 * 256;   // PT[3], WAll[nb], LT[2], DG[2], CR[2]
   const size_t buildA = (size_t)(((D + 3) & ~3) + 4) * np + (nb == 16 ? 24 * 256 : 0);   // staged points (+ tail rows) + the panel wave's tile images (N > 128 only)
   if (buildA > regionA) regionA = buildA;
   // + vectors, trash/exp table, row lists, 1/l, fail flag + 6 nb hand-off counters (ints)
-  return (regionA + 4 * np + 160 + (size_t)wu * nb * 4 + (size_t)wu * 16 + D + (D & 1) + 2 + 3 * (size_t)nb) * sizeof(double);
+  return (regionA + 3 * np + 160 + (size_t)wu * nb * 4 + D + (D & 1) + 2 + 3 * (size_t)nb) * sizeof(double);
 }
 
 }  // namespace
@@ -167,7 +167,7 @@ int scaml_fit_max_n(void) { return 256; }
 int scaml_fit_max_d(int N) {
   // largest D whose staged point stack fits the 160 KiB LDS next to the vectors
   int np = N <= 32 ? 32 : (N <= 64 ? 64 : (N <= 128 ? 128 : 256));
-  int budget = 160 * 1024 / 8 - 4 * np - 160 - 7 * 16 * 4 - 7 * 16 - 3 * 16 - 4 - (np == 256 ? 24 * 256 : 0);
+  int budget = 160 * 1024 / 8 - 3 * np - 160 - 7 * 16 * 4 - 3 * 16 - 4 - (np == 256 ? 24 * 256 : 0);
   int d = ((budget / (np + 1)) & ~3) - 4;   // rows: D rounded up to 4, + 4 tail rows; + 1/l per dimension
   return d > 1024 ? 1024 : d;
 }
