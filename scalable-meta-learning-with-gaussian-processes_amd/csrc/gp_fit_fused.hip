@@ -752,6 +752,12 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       __builtin_amdgcn_s_setprio(0);
     } else {
       // ================= update waves ================================================================
+#ifndef SCAML_YOUNG_PRIO
+#define SCAML_YOUNG_PRIO 1
+#endif
+      // (the second wave of a SIMD loses the issue arbitration to its older mate in every phase and is the iteration's
+      //  long pole: a static raise for that half -- 107.7 -> 107.0 us in interleaved A/B, priority 2 the same)
+      if (WU == 7 && wave >= 4) __builtin_amdgcn_s_setprio(SCAML_YOUNG_PRIO);
       auto store_column = [&](int c) {
         if (Lg && c >= PSTORE) {
           const int sa = slo(c), sb = slo(c + 1), offc = off(c);
@@ -824,7 +830,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
           // one switch and then falling through slot after slot (the parked D_{k+2} is skipped).
           // Round 2: U2(k) runs BEFORE F(k+1) -- the time a wave used to spend in front of flagW[k+1] waiting for the
           // panel wave (1.4-2.9 k cycles per iteration) is bulk work now; cntT[k+1] arrives later, but nobody needs it
-          // before his own U2(k) is through (109.2 -> 105 us in interleaved A/B; round 1 had F first).
+          // before his own U2(k) is through (109.2 -> 108.0 us in interleaved A/B; round 1 had F first).
           const int s0 = slo(k + 2);
           int uj = k + 2, ur = s0 * WU + wave - off(k + 2);
 #define SCAML_U2_(S, r0, r1, r2, r3, r4, r5, r6, r7)                                               \
