@@ -327,8 +327,27 @@ __device__ __forceinline__ int potf2_inv_block(d4_t a, double* LT, double* Wt, d
 // The kernel inlines this once for the first attempt (straight-line: nothing loop-invariant can be
 // hoisted out of the kernel-matrix build and stay live across the panel loop) and calls the
 // out-of-line copy below for the rare jitter retries.
-template <int NB, int WU, int KIND>
-__device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double jitter) {
+// addressing of the task's arrays: dense (everything follows from N) or given (blocked fit)
+template <bool BLK>
+struct FitBlk {
+  __device__ __forceinline__ int ldl(int N) const { return N; }
+  __device__ __forceinline__ size_t sx(size_t dense) const { return dense; }
+  __device__ __forceinline__ size_t sy(size_t dense) const { return dense; }
+  __device__ __forceinline__ size_t sL(size_t dense) const { return dense; }
+  __device__ __forceinline__ size_t sW(size_t dense) const { return dense; }
+};
+template <>
+struct FitBlk<true> {
+  FitBlockParams v;
+  __device__ __forceinline__ int ldl(int) const { return v.ldl; }
+  __device__ __forceinline__ size_t sx(size_t) const { return (size_t)v.stride_x; }
+  __device__ __forceinline__ size_t sy(size_t) const { return (size_t)v.stride_y; }
+  __device__ __forceinline__ size_t sL(size_t) const { return (size_t)v.stride_L; }
+  __device__ __forceinline__ size_t sW(size_t) const { return (size_t)v.stride_W; }
+};
+
+template <int NB, int WU, int KIND, bool BLK>
+__device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double jitter, const FitBlk<BLK> b) {
   constexpr int NP = NB * 16;                 // padded matrix order
   constexpr int NT = NB * (NB + 1) / 2;       // lower-triangular tiles
   constexpr int SLOTS = (NT + WU - 1) / WU;   // tiles per update wave
@@ -376,19 +395,20 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   const int lc = lane & 15;   // tile column owned by this lane
   const int lq = lane >> 4;   // tile row group: rows lq + 4 * reg
   const int N = p.N, D = p.D;
+  const int LD = b.ldl(N);   // leading dimension of the stored factor (N, or the full size when this is a diagonal block of a blocked fit)
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
   const bool from_matrix = p.A_in != nullptr;   // POTRF mode: the matrix is given, nothing to evaluate
   const double* Ag = from_matrix ? p.A_in + (size_t)task * N * N : nullptr;
-  const double* Xg = from_matrix ? nullptr : p.X + (size_t)task * N * D;
-  const double* yg = p.y ? p.y + (size_t)task * N : nullptr;
+  const double* Xg = from_matrix ? nullptr : p.X + (size_t)task * b.sx((size_t)N * D);
+  const double* yg = p.y ? p.y + (size_t)task * b.sy((size_t)N) : nullptr;
   const double* th = from_matrix ? nullptr : p.theta + (size_t)task * (D + 2);
   const double os = from_matrix ? 1.0 : th[D];
   const double noise = from_matrix ? 0.0 : th[D + 1];
   const double jit_in = p.jitter_in ? p.jitter_in[task] : 0.0;
-  double* Lg = (p.flags & SCAML_FIT_STORE_L) ? p.L + (size_t)task * N * N : nullptr;
+  double* Lg = (p.flags & SCAML_FIT_STORE_L) ? p.L + (size_t)task * b.sL((size_t)N * N) : nullptr;
   const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
-  const int lane_idx = lq * N + lc;  // element offset of this lane inside a 16x16 tile of L (row-major, ld = N)
+  const int lane_idx = lq * LD + lc;  // element offset of this lane inside a 16x16 tile of L (row-major, ld = LD)
 
   // Tiles in column-major order over the lower triangle: column j starts at tile off(j); this wave
   // owns tiles t = s * WU + wave (slot s), so its tiles of column j are the contiguous slots
@@ -597,21 +617,21 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     auto store_tile = [&](int c, int ti) {
       const double* prow = PT + (c % 3) * PANEL + (16 * ti + lq) * PP + lc;
       const double e[4] = {prow[0], prow[4 * PP], prow[8 * PP], prow[12 * PP]};
-      double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c);   // tile (ti, c), wave-uniform
-      double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti);   // mirrored tile (c, ti)
+      double* tb = Lg + ((size_t)(16 * ti) * LD + 16 * c);   // tile (ti, c), wave-uniform
+      double* mb = Lg + ((size_t)(16 * c) * LD + 16 * ti);   // mirrored tile (c, ti)
       if (16 * ti + 16 <= n) {                              // interior tile: no per-lane bounds
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          tb[(size_t)g * 4 * N + lane_idx] = e[g];
-          if (zero_upper) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+          tb[(size_t)g * 4 * LD + lane_idx] = e[g];
+          if (zero_upper) mb[(size_t)g * 4 * LD + lane_idx] = 0.0;
         }
       } else {
         const int col = 16 * c + lc, mc = 16 * ti + lc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = 16 * ti + lq + 4 * g, mr = 16 * c + lq + 4 * g;
-          if (row < n && col < n) tb[(size_t)g * 4 * N + lane_idx] = e[g];
-          if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * N + lane_idx] = 0.0;
+          if (row < n && col < n) tb[(size_t)g * 4 * LD + lane_idx] = e[g];
+          if (zero_upper && mr < n && mc < n) mb[(size_t)g * 4 * LD + lane_idx] = 0.0;
         }
       }
     };
@@ -708,15 +728,15 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
             double e[4 * SCAML_STRIP];
 #pragma unroll
             for (int u = 0; u < 4 * SCAML_STRIP; ++u) e[u] = prow[4 * u * PP];
-            double* tb = Lg + ((size_t)(16 * ti) * N + 16 * c) + lane_idx;
+            double* tb = Lg + ((size_t)(16 * ti) * LD + 16 * c) + lane_idx;
 #pragma unroll
-            for (int u = 0; u < 4 * SCAML_STRIP; ++u) tb[(size_t)4 * u * N] = e[u];
+            for (int u = 0; u < 4 * SCAML_STRIP; ++u) tb[(size_t)4 * u * LD] = e[u];
             if (zero_upper) {
-              double* mb = Lg + ((size_t)(16 * c) * N + 16 * ti) + lane_idx;
+              double* mb = Lg + ((size_t)(16 * c) * LD + 16 * ti) + lane_idx;
 #pragma unroll
               for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int u = 0; u < SCAML_STRIP; ++u) mb[(size_t)g * 4 * N + 16 * u] = 0.0;
+                for (int u = 0; u < SCAML_STRIP; ++u) mb[(size_t)g * 4 * LD + 16 * u] = 0.0;
             }
           }
           for (; ti < NB; ++ti) store_tile(c, ti);
@@ -772,13 +792,13 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       auto store_diag = [&](int c) {
         if (Lg && off(c) % WU == wave) {
           const double* lt = LT + (c & 1) * 16 * PP + lq * PP + lc;
-          double* tb = Lg + ((size_t)(16 * c) * N + 16 * c);
+          double* tb = Lg + ((size_t)(16 * c) * LD + 16 * c);
           const int col = 16 * c + lc;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int row = 16 * c + lq + 4 * g;
             const double e = lt[4 * g * PP];
-            if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * N + lane_idx] = e;
+            if (row < n && col < n && (zero_upper || col <= row)) tb[(size_t)g * 4 * LD + lane_idx] = e;
           }
         }
       };
@@ -951,7 +971,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       // W_k = L_kk^-1 for every diagonal block, (T, ceil(N/16), 16, 16): the batched posterior solves
       // L^-1 K_*^T with them on the matrix cores instead of by substitution
       const int nbn = (N + 15) / 16;
-      double* Wg = p.Linv_diag + (size_t)task * nbn * 256;
+      double* Wg = p.Linv_diag + (size_t)task * b.sW((size_t)nbn * 256);
       for (int e = tid; e < nbn * 256; e += NTHREADS)   // W[r][c] of block b = WAll[b][c][r] (kept transposed)
         Wg[e] = WAll[(e >> 8) * 16 * PP + (e & 15) * PP + ((e >> 4) & 15)];
     }
@@ -1070,7 +1090,7 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       }
       __syncthreads();
       STAMP(14);
-      for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * N + r] = dl[r];
+      for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * b.sy((size_t)N) + r] = dl[r];
     }
   }
   STAMP(10);
@@ -1081,22 +1101,22 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
   return fail;
 }
 
-template <int NB, int WU, int KIND>
-__device__ __noinline__ int gp_fit_retry(const FitParams& p, const double jitter) {
-  return gp_fit_attempt<NB, WU, KIND>(p, jitter);
+template <int NB, int WU, int KIND, bool BLK>
+__device__ __noinline__ int gp_fit_retry(const FitParams& p, const double jitter, const FitBlk<BLK> b) {
+  return gp_fit_attempt<NB, WU, KIND, BLK>(p, jitter, b);
 }
 
-template <int NB, int WU, int KIND>
-__global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p) {
+template <int NB, int WU, int KIND, bool BLK>
+__device__ __forceinline__ void gp_fit_main(const FitParams& p, const FitBlk<BLK> b) {
   // jitter escalation of linear_operator's psd_safe_cholesky, per task, without leaving the GPU
   double jitter = 0.0;
-  int fail = gp_fit_attempt<NB, WU, KIND>(p, 0.0);
+  int fail = gp_fit_attempt<NB, WU, KIND, BLK>(p, 0.0, b);
 #ifndef SCAML_STAMPS  // (the diagnostic build times the first attempt only)
   if (fail && !(p.flags & SCAML_FIT_NO_RETRY)) {
     const FitParams pc = p;  // only this cold copy has its address taken; `p` stays in the kernarg segment
     for (int attempt = 1; attempt < 4 && fail; ++attempt) {
       jitter = attempt == 1 ? 1e-8 : (attempt == 2 ? 1e-7 : 1e-6);
-      fail = gp_fit_retry<NB, WU, KIND>(pc, jitter);
+      fail = gp_fit_retry<NB, WU, KIND, BLK>(pc, jitter, b);
     }
   }
 #endif
@@ -1113,13 +1133,27 @@ __global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p
   }
 }
 
+template <int NB, int WU, int KIND>
+__global__ __launch_bounds__((WU + 1) * 64) void gp_fit_fused_kernel(FitParams p) {
+  gp_fit_main<NB, WU, KIND, false>(p, FitBlk<false>{});
+}
+
+// the same fit in place on a diagonal block of a larger task (strided addressing; tasks may be switched off)
+template <int NB, int WU, int KIND>
+__global__ __launch_bounds__((WU + 1) * 64) void gp_fit_blocked_kernel(FitParams p, FitBlockParams bp) {
+  if (bp.active && bp.active[blockIdx.x] == 0) return;   // (jitter rounds: this task is already done)
+  gp_fit_main<NB, WU, KIND, true>(p, FitBlk<true>{bp});
+}
+
 }  // namespace scaml
 
 // Explicit instantiations: one kernel per padded size class (NB 16-blocks, WU update waves) and
 // kernel kind (see VGPR_CAPS in __graft_entry__.py for the register budgets).
 #define SCAML_INSTANTIATE(NB, WU)                                                   \
   template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 0>(scaml::FitParams); \
-  template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 1>(scaml::FitParams);
+  template __global__ void scaml::gp_fit_fused_kernel<NB, WU, 1>(scaml::FitParams); \
+  template __global__ void scaml::gp_fit_blocked_kernel<NB, WU, 0>(scaml::FitParams, scaml::FitBlockParams); \
+  template __global__ void scaml::gp_fit_blocked_kernel<NB, WU, 1>(scaml::FitParams, scaml::FitBlockParams);
 SCAML_INSTANTIATE(2, 1)
 SCAML_INSTANTIATE(4, 3)
 SCAML_INSTANTIATE(8, 3)

@@ -23,4 +23,15 @@ struct FitParams {
   unsigned flags;
 };
 
+// Second argument of gp_fit_blocked_kernel: the same fit run IN PLACE on a diagonal block of a larger task
+// (csrc/gp_fit_blocked.hip).  A plain fit has ldl = N, stride_x = N D, stride_y = N, stride_L = N N, stride_W = ceil(N/16) 256.
+struct FitBlockParams {
+  long long stride_x;       // doubles between the tasks' point sets
+  long long stride_y;       // ... between the tasks' targets (and alphas)
+  long long stride_L;       // ... between the tasks' factors
+  long long stride_W;       // ... between the tasks' stacks of inverted diagonal blocks
+  const int32_t* active;    // (T) or NULL: tasks with active[t] == 0 are left untouched
+  int ldl;                  // leading dimension of L
+};
+
 }  // namespace scaml

@@ -34,15 +34,14 @@ constexpr int PP = 17;  // LDS panel pitch, must match csrc/gp_fit_fused.hip
 
 struct FitVariant {
   int nb, wu;
-  hipFunction_t fn[2];  // [kind]
+  hipFunction_t fn[2][2];  // [kind][dense | blocked addressing]
 };
 
 struct Module {
   std::mutex mu;
   bool loaded = false;
   hipModule_t mod = nullptr;
-  FitVariant fit[5] = {{2, 1, {nullptr, nullptr}}, {4, 3, {nullptr, nullptr}}, {8, 3, {nullptr, nullptr}}, {16, 7, {nullptr, nullptr}},
-                       {8, 7, {nullptr, nullptr}}};   // [4]: wide variant for 64 < N <= 128
+  FitVariant fit[5] = {{2, 1, {}}, {4, 3, {}}, {8, 3, {}}, {16, 7, {}}, {8, 7, {}}};   // [4]: wide variant for 64 < N <= 128
   int num_cus = 0;
   hipFunction_t post[2] = {nullptr, nullptr};
   hipFunction_t post_cov[2] = {nullptr, nullptr};
@@ -63,13 +62,15 @@ struct Module {
     hipError_t e = hipModuleLoadData(&mod, scaml_hsaco_blob);
     if (e != hipSuccess) return e;
     for (auto& v : fit) {
-      for (int kind = 0; kind < 2; ++kind) {
+      for (int kb = 0; kb < 4; ++kb) {
+        const int kind = kb >> 1, blk = kb & 1;
         char name[128];
-        snprintf(name, sizeof(name), "_ZN5scaml19gp_fit_fused_kernelILi%dELi%dELi%dEEEvNS_9FitParamsE", v.nb, v.wu, kind);
-        e = hipModuleGetFunction(&v.fn[kind], mod, name);
+        if (blk) snprintf(name, sizeof(name), "_ZN5scaml21gp_fit_blocked_kernelILi%dELi%dELi%dEEEvNS_9FitParamsENS_14FitBlockParamsE", v.nb, v.wu, kind);
+        else snprintf(name, sizeof(name), "_ZN5scaml19gp_fit_fused_kernelILi%dELi%dELi%dEEEvNS_9FitParamsE", v.nb, v.wu, kind);
+        e = hipModuleGetFunction(&v.fn[kind][blk], mod, name);
         if (e != hipSuccess) return e;
         // the kernels use up to the full 160 KiB of LDS
-        e = hipFuncSetAttribute((const void*)v.fn[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        e = hipFuncSetAttribute((const void*)v.fn[kind][blk], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
       }
     }
@@ -172,7 +173,7 @@ int scaml_fit_max_d(int N) {
   return d > 1024 ? 1024 : d;
 }
 
-static int fit_common(scaml::FitParams p, int kind, void* stream) {
+static int fit_common(scaml::FitParams p, int kind, void* stream, const scaml::FitBlockParams* blk = nullptr) {
   Module& m = module();
   hipError_t e = m.load();
   if (e != hipSuccess) {
@@ -194,9 +195,10 @@ static int fit_common(scaml::FitParams p, int kind, void* stream) {
   const FitVariant& v = m.fit[vi];
   const size_t lds = fit_lds_bytes(v.nb, v.wu, p.D);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
-  size_t psize = sizeof(p);
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
-  e = hipModuleLaunchKernel(v.fn[kind], (unsigned)p.T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
+  struct { scaml::FitParams p; scaml::FitBlockParams b; } args{p, blk ? *blk : scaml::FitBlockParams{}};   // (kernarg layout: both 8-byte aligned)
+  size_t psize = blk ? sizeof(args) : sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(v.fn[kind][blk ? 1 : 0], (unsigned)p.T, 1, 1, (unsigned)(v.wu + 1) * 64, 1, 1, (unsigned)lds,
                             (hipStream_t)stream, nullptr, config);
   if (e != hipSuccess) {
     set_error("hipModuleLaunchKernel(gp_fit_fused)", e);
