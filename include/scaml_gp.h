@@ -78,6 +78,30 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
                            int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags, void* stream);
 
 /*
+ * (3b) The same fit for scaml_fit_max_n() < N <= scaml_fit_blocked_max_n() points per task (the 512-point source
+ * tasks of scamlgp/benchmarking/configurations/hartmann6_ablation_num_points_per_task.py:17-18, fitted in the
+ * reference by the same scamlgp/model.py:176-188 / scamlgp/utils.py:171-177 chain): a 2 x 2 block factorisation
+ * enqueued as one sequence of launches -- fused fit of the first 256 points in place, L21 = (L11^-1 K12)^T by column
+ * strips, Schur complement, fused factorisation of the Schur complement in place, alpha / MLL assembly -- with no
+ * host synchronisation and nothing but this library's kernels on the stream.  Arguments, outputs and the jitter
+ * ladder (one value for the whole matrix of a failing task: 0, 1e-8, 1e-7, 1e-6) are those of
+ * scaml_gp_fit_fused_f64; info[t] = k > 0 counts pivots over the full matrix.  Requirements: N a multiple of 16,
+ * D <= scaml_fit_blocked_max_d(); L, alpha, info and Linv_diag must be given (the later launches read the earlier
+ * ones' results from them), SCAML_FIT_STORE_L is implied.  `workspace` is device memory of at least
+ * scaml_gp_fit_blocked_workspace_bytes(T, N) bytes, 16-byte aligned, owned by the caller and free again when the
+ * stream has passed the call.  Returns SCAML_E_TOOLARGE for shapes it does not take.
+ */
+int scaml_fit_blocked_max_n(void);
+int scaml_fit_blocked_max_d(void);
+long long scaml_gp_fit_blocked_workspace_bytes(int T, int N);
+int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* theta,
+                             const int32_t* n_points, const double* jitter_in,
+                             int T, int N, int D, int kind,
+                             double* L, double* alpha, double* quad, double* logdet, double* mll,
+                             int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags,
+                             void* workspace, long long workspace_bytes, void* stream);
+
+/*
  * (1) Stand-alone kernel matrix K[t] = os_t k(X1_t / l_t, X2_t / l_t), (T, N1, N2).  X2 == NULL means
  * X2 = X1 (N2 must equal N1; with add_noise != 0 the noise variance is added to the diagonal: the
  * training matrix of scamlgp/model.py:36-70 + :25-33); x2_shared != 0 means X2 is one (N2, D) set

@@ -1,0 +1,470 @@
+// gp_fit_blocked.hip — the fused fit for 256 < N <= 512 points per task as a 2 x 2 block factorisation, all on the
+// device (gfx950): no host synchronisation, no framework ops between the launches.
+//
+//        [K11 K12]   [L11      ] [L11^T L21^T]      L11  = fused fit of block 1, in place     (gp_fit_blocked_kernel, 1 CU / task)
+//        [K21 K22] = [L21   L22] [      L22^T]      L21^T = L11^-1 K12, r2 = y2 - K21 alpha1'  (gp_blocked_solve_kernel, 4 CUs / task)
+//                                                   S    = K22 + (noise + jitter) I - L21 L21^T (gp_blocked_syrk_kernel, 10 CUs / task)
+//                                                   L22  = chol(S), alpha2 = S^-1 r2, in place  (gp_fit_blocked_kernel on S)
+//                                                   alpha1 = alpha1' - L11^-T (L21^T alpha2), MLL (gp_blocked_finish_kernel)
+//
+// The reference fits source GPs of up to 512 points (scamlgp/benchmarking/configurations/
+// hartmann6_ablation_num_points_per_task.py:17-18) with gpytorch's ExactGP (kernel matrix -> psd_safe_cholesky ->
+// cholesky_solve); a 512 x 512 task does not fit the registers + LDS of one CU, which is what the single-launch kernel
+// lives on.  The jitter ladder of psd_safe_cholesky (one jitter value for the whole matrix of a failing task) is kept
+// exact: every launch of a round is single-shot; the launches of rounds 1-3 are enqueued unconditionally, and
+// gp_blocked_round_kernel switches off (active[t] = 0) every task that is already factored, so that they cost an
+// empty launch each when nothing failed.
+#include "../../include/scaml_gp.h"
+#include "gf_tiles.hpp"
+#include "gp_fit_params.h"
+
+namespace scaml {
+
+constexpr int BK_N1 = 256;   // block 1: what the single-launch kernel takes
+constexpr int BK_NB1 = 16;
+
+// ---- round prologue: per-task sizes of the two blocks, the round's jitter, and who still has to run -------------------
+extern "C" __global__ void scaml_blocked_round_kernel(BlockedFitParams p) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.T) return;
+  const double base = p.jitter_in ? p.jitter_in[t] : 0.0;
+  if (p.round == 0) {
+    int n = p.n_points ? p.n_points[t] : p.N;
+    n = n < 0 ? 0 : (n > p.N ? p.N : n);
+    p.n1[t] = n < BK_N1 ? n : BK_N1;
+    p.n2[t] = n > BK_N1 ? n - BK_N1 : 0;
+    p.active[t] = 1;
+    p.jit_ladder[t] = 0.0;
+    p.jit_cur[t] = base;
+    p.info1[t] = 0;
+    p.info2[t] = 0;
+  } else {
+    const bool failed = p.info1[t] > 0 || p.info2[t] > 0;
+    p.active[t] = failed ? 1 : 0;
+    if (failed) {
+      const double j = p.round == 1 ? 1e-8 : (p.round == 2 ? 1e-7 : 1e-6);   // psd_safe_cholesky's escalation
+      p.jit_ladder[t] = j;
+      p.jit_cur[t] = base + j;
+      p.info2[t] = 0;   // (block 2 is not attempted when block 1 fails again: no stale status)
+    }
+  }
+}
+
+// Workgroup -> (task, part) for the kernels that give a task several workgroups.  Workgroups are dealt to the 8 XCDs
+// round-robin by their linear index; task t is kept on XCD t % 8 -- where its fused fits run (one workgroup per task,
+// index t) -- so that what one launch leaves in that XCD's L2 is what the next one reads.  grid.x = 8 ceil(T/8) parts.
+__device__ __forceinline__ bool bk_task_part(int parts, int T, int& task, int& part) {
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  task = (idx / parts) * 8 + xcd;
+  part = idx % parts;
+  return task < T;
+}
+
+// squared scaled distance of two staged points (difference form)
+__device__ __forceinline__ double bk_sqdist(const double* a, const double* b, int D) {
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double u = a[d] - b[d];
+    s = __builtin_fma(u, u, s);
+  }
+  return s;
+}
+
+// ---- L21^T = L11^-1 K12 by column strips, r2 = y2 - K21 alpha1' --------------------------------------------------------
+// One wave owns one strip (16 points of block 2): its 16 blocks Z_0..Z_15 live in hand-managed AGPRs in the MFMA C/D
+// layout = the B-operand layout (csrc/gf_tiles.hpp), so a finished block feeds the next products from the registers it
+// was computed in.  The four waves of a workgroup advance in lockstep over the block rows of L11; row block kb (with
+// W_kb = L_kb,kb^-1 in place of the diagonal block) is staged once per workgroup in LDS by global_load_lds_dwordx4, one
+// step ahead.  Step kb:  ACC = K12 block (kernel function, VALU);  ACC -= L[kb][j] Z_j, j < kb;  Z_kb = W_kb ACC.
+template <int KB>
+__device__ __forceinline__ void bk_solve_step(const double* pa) {
+  GfOps cur = gf_load_ops(pa, 4);
+  gf_fwd_chain<KB, BK_NB1, false>(cur, 0, pa);
+  GF_DRAIN();
+  GfTile<gf_slot<BK_NB1, false>(KB)>::set_prod_acc(cur.a0, cur.a1, cur.a2, cur.a3);
+}
+
+// The finished strip leaves the registers twice: as register images for the Schur-complement kernel (workspace), and as
+// rows of L21 -- transposed through the (by now free) LDS staging area in two halves of eight blocks, so that every
+// global store is 1 KB of one row (the direct store would scatter 32-byte pieces over 16 rows 4 KB apart).
+constexpr int BK_TP = 132;   // LDS pitch of a transposed half row (128 columns)
+template <int J, int J1>
+__device__ __forceinline__ void bk_stage_strip(double* tr, double* img, bool col_ok, int lc, int lq) {
+  // tr[lc][16 (J mod 8) + lq + 4 g] = L21[16 c + lc][16 J + lq + 4 g] = Z_J[lq + 4 g][lc]
+  d4_t z = GfTile<gf_slot<BK_NB1, false>(J)>::get();
+  if (!col_ok) z = d4_t{0.0, 0.0, 0.0, 0.0};
+  if (img) {   // the block as the matrix core holds it (lane-major, 32 bytes per lane)
+    double2* q = reinterpret_cast<double2*>(img + J * 256);
+    q[0] = double2{z[0], z[1]};
+    q[1] = double2{z[2], z[3]};
+  }
+  double* t = tr + lc * BK_TP + 16 * (J & 7) + lq;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) t[4 * g] = z[g];
+  if constexpr (J + 1 < J1) bk_stage_strip<J + 1, J1>(tr, img, col_ok, lc, lq);
+}
+
+#define BK_STEP_CASE(K) case K: bk_solve_step<K>(pa); break;
+
+// SMALLD (D <= 8): the points are staged zero-padded to 8 dimensions, the lane's own block-2 point sits in registers and
+// the distance loops have a constant trip count.
+template <int KIND, bool SMALLD>
+__global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams p) {
+  constexpr int NP = BK_N1, PA = NP + 2, BUF = 16 * PA, NW = 4, TPB = 256;
+  extern __shared__ double lds[];
+  const int N = p.N, D = p.D;
+  const int DP = SMALLD ? 9 : (D | 1);   // odd pitch of the staged points
+  const int DS = SMALLD ? 8 : D;         // staged dimensions
+  double* buf = lds;                     // [3][BUF]: row blocks of L11, two steps ahead
+  double* X1s = buf + 3 * BUF;           // [NP][DP] block-1 points / lengthscale
+  double* X2s = X1s + NP * DP;           // [64][DP] this workgroup's block-2 points / lengthscale
+  double* a1s = X2s + 64 * DP;           // [NP] alpha1'
+  double* exptab = a1s + NP;             // [64]
+  double* invl = exptab + 64;            // [DS]
+
+  int task, sg;
+  if (!bk_task_part((N - BK_N1 + 63) / 64, p.T, task, sg)) return;
+  if (p.active[task] == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, lq = lane >> 4;
+  const int n1 = p.n1[task], n2 = p.n2[task];
+  const int NBT = (N + 15) / 16;
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * NBT * 256;
+  const double* Xg = p.X + (size_t)task * N * D;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double os = th[D];
+
+  typedef __attribute__((address_space(1))) void gvoid_t;
+  typedef __attribute__((address_space(3))) void lvoid_t;
+  // row block kb of L11: 16 kb columns of L, then the 16 of W_kb (16-byte pieces; N % 16 == 0).  A wave moves four rows:
+  // 4 wave-instructions for kb <= 7, 8 beyond (the step loop counts them in its s_waitcnt).
+  auto dma_step = [&](int kb) {
+    double* b = buf + (kb % 3) * BUF;
+    constexpr int RPW = 16 / NW;
+    const int nch = 8 * kb + 8;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int r = wave * RPW + rr;
+      const double* lrow = Lg + (size_t)(16 * kb + r) * N;
+      const double* wrow = Wg + (size_t)kb * 256 + r * 16 - 16 * kb;
+      for (int c0 = 0; c0 < nch; c0 += 64) {
+        const int ch = c0 + lane;
+        const int chc = ch < nch ? ch : nch - 1;   // (lanes past the row re-fetch its last piece into a slot nobody reads: one instruction per 64 pieces, always)
+        const double* src = (chc < 8 * kb ? lrow : wrow) + 2 * chc;
+        __builtin_amdgcn_global_load_lds((const gvoid_t*)src, (lvoid_t*)(b + r * PA + 2 * c0), 16, 0, 0);
+      }
+    }
+  };
+
+  dma_step(0);
+  dma_step(1);
+  exp2_table_init(exptab, tid);
+  if (tid < DS) invl[tid] = tid < D ? 1.0 / th[tid] : 0.0;
+  __syncthreads();
+  for (int e = tid; e < NP * DS; e += TPB) {
+    const int r = e / DS, d = e - r * DS;
+    X1s[r * DP + d] = (r < n1 && d < D) ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+  }
+  for (int e = tid; e < 64 * DS; e += TPB) {
+    const int q = e / DS, d = e - q * DS, pt = 64 * sg + q;
+    X2s[q * DP + d] = (pt < n2 && d < D) ? Xg[(size_t)(BK_N1 + pt) * D + d] * invl[d] : 0.0;
+  }
+  for (int r = tid; r < NP; r += TPB) a1s[r] = r < n1 ? p.alpha[(size_t)task * N + r] : 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int c = 4 * sg + wave;              // this wave's strip
+  const int colpt = 16 * c + lc;            // its point on this lane (index inside block 2)
+  const bool col_ok = colpt < n2;
+  const double* xc = X2s + (16 * wave + lc) * DP;
+  double xcr[8];
+  if constexpr (SMALLD) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) xcr[d] = xc[d];
+  }
+  double macc = 0.0;                        // lane's share of K21 alpha1' at its point
+  for (int kb = 0; kb < BK_NB1; ++kb) {
+    if (kb + 2 < BK_NB1) dma_step(kb + 2);  // into the buffer step kb - 1 read from: everybody is past the barrier that ended it
+    double kv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + lq + 4 * g;
+      double d2;
+      if constexpr (SMALLD) {
+        const double* xr = X1s + row * 9;
+        d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const double uu = xr[d] - xcr[d];
+          d2 = __builtin_fma(uu, uu, d2);
+        }
+      } else {
+        d2 = bk_sqdist(X1s + row * DP, xc, D);
+      }
+      const double k = os * kernel_from_sqdist<KIND>(d2, exptab);
+      kv[g] = (row < n1 && col_ok) ? k : 0.0;
+      macc = __builtin_fma(kv[g], a1s[row], macc);
+    }
+    GF_DRAIN();   // (the previous step's closing product may still be reading ACC)
+    gf_acc_set(kv[0], kv[1], kv[2], kv[3]);
+    const double* pa = buf + (kb % 3) * BUF + lc * PA + lq;   // A operand: L[16 kb + lc][16 j + lq + 4 m]
+    switch (kb) {
+      BK_STEP_CASE(0) BK_STEP_CASE(1) BK_STEP_CASE(2) BK_STEP_CASE(3) BK_STEP_CASE(4) BK_STEP_CASE(5) BK_STEP_CASE(6) BK_STEP_CASE(7)
+      BK_STEP_CASE(8) BK_STEP_CASE(9) BK_STEP_CASE(10) BK_STEP_CASE(11) BK_STEP_CASE(12) BK_STEP_CASE(13) BK_STEP_CASE(14)
+      BK_STEP_CASE(15)
+      default: break;
+    }
+    // this wave's pieces of row block kb + 1 have landed; those of kb + 2 (4 or 8 instructions, issued above) may be in flight
+    if (kb + 2 >= BK_NB1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (kb + 2 >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __syncthreads();
+  }
+  GF_DRAIN();
+  // the strip goes to memory as rows of L21 (and, on request, zeros into the mirrored block of the upper triangle)
+  const int N2 = N - BK_N1;
+  const bool in_matrix = colpt < N2;
+  double* Lw = p.L + (size_t)task * N * N;
+  double* urow = in_matrix ? Lw + BK_N1 + colpt : nullptr;
+  double* img = in_matrix || 16 * c < N2 ? p.Vimg + ((size_t)task * BK_NB1 + c) * BK_NB1 * 256 + lane * 4 : nullptr;
+  double* tr = buf + wave * (16 * BK_TP);   // (everybody is past the barrier that ended the last step: the staging area is free)
+  const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
+  const bool strip_in = 16 * c < N2;        // (N2 is a multiple of 16: a strip is inside the matrix or not at all)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) bk_stage_strip<0, 8>(tr, img, col_ok, lc, lq);
+    else bk_stage_strip<8, 16>(tr, img, col_ok, lc, lq);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (strip_in) {
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const double2 v = *reinterpret_cast<const double2*>(tr + i * BK_TP + 2 * lane);
+        *reinterpret_cast<double2*>(Lw + (size_t)(BK_N1 + 16 * c + i) * N + 128 * h + 2 * lane) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (zero_upper && urow) {
+    for (int r = lq; r < BK_N1; r += 4) urow[(size_t)r * N] = 0.0;   // the mirrored block of the upper triangle: 128-byte row pieces
+  }
+  macc = sum_lane_groups(macc);
+  if (lq == 0 && in_matrix) p.r2[(size_t)task * N + BK_N1 + colpt] = col_ok ? p.y[(size_t)task * N + BK_N1 + colpt] - macc : 0.0;
+}
+#undef BK_STEP_CASE
+
+// ---- S = K22 + (noise + jitter) I - L21 L21^T, lower 64 x 64 tiles, one workgroup (8 waves) each -------------------------
+// Wave (w, ks) of a tile takes block column w (16 columns), the four row blocks and half ks of the summation index; both
+// MFMA operands are the blocks of L21^T as the strip solve left them in the workspace (register images: a wave load is
+// 2 KB of consecutive memory -- rows of L21 itself are 4 KB apart, 16 of them per load land on one L2 channel).
+// The loads of four block rows (40 x 16 bytes per lane) are issued together: two memory round trips per wave.  The two halves
+// swap partial sums through LDS; each finishes two of the four blocks (kernel function, diagonal, store).
+template <int KIND>
+__global__ __launch_bounds__(512, 4) void gp_blocked_syrk_kernel(BlockedFitParams p) {
+  extern __shared__ double lds[];
+  const int N = p.N, D = p.D, N2 = N - BK_N1;
+  const int DP = D | 1;
+  double* xch = lds;                // [8 waves][2 blocks][4][64] partial sums handed to the partner wave
+  double* Xr = xch + 8 * 512;       // [64][DP] the tile's row points / lengthscale
+  double* Xc = Xr + 64 * DP;        // [64][DP] column points
+  double* exptab = Xc + 64 * DP;    // [64]
+  double* invl = exptab + 64;       // [D]
+  const int nt = (N2 + 63) / 64;
+  int task, tile;
+  if (!bk_task_part(nt * (nt + 1) / 2, p.T, task, tile)) return;
+  if (p.active[task] == 0) return;
+  int bi = 0, rem = tile;           // linear index over the lower triangle of tiles, row by row
+  while (rem > bi) { rem -= bi + 1; ++bi; }
+  const int bj = rem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = wave & 3, ks = wave >> 2;
+  const int lc = lane & 15, lq = lane >> 4;
+  const double* Xg = p.X + (size_t)task * N * D;
+  const double* th = p.theta + (size_t)task * (D + 2);
+  const double os = th[D], diag_add = th[D + 1] + p.jit_cur[task];
+  exp2_table_init(exptab, tid);
+  if (tid < D) invl[tid] = 1.0 / th[tid];
+  __syncthreads();
+  for (int e = tid; e < 64 * D; e += 512) {
+    const int q = e / D, d = e - q * D;
+    const int pr = 64 * bi + q, pc = 64 * bj + q;
+    Xr[q * DP + d] = pr < N2 ? Xg[(size_t)(BK_N1 + pr) * D + d] * invl[d] : 0.0;
+    Xc[q * DP + d] = pc < N2 ? Xg[(size_t)(BK_N1 + pc) * D + d] * invl[d] : 0.0;
+  }
+  const int cb = 4 * bj + w;
+  const bool live = 16 * cb < N2;   // (a block column past the matrix: the wave only keeps the barriers company)
+  // block (kb, strip) of L21^T as the strip solve left it: 64 lanes x 32 bytes, register m of the image = operand of step m
+  // on either side (A = block^T in the A layout, B = block in the B layout: the same registers)
+  auto imgp = [&](int strip) { return p.Vimg + (((size_t)task * BK_NB1 + (strip < BK_NB1 ? strip : BK_NB1 - 1)) * BK_NB1 + 8 * ks) * 256 + lane * 4; };
+  const double* bp = imgp(cb);
+  const double* ap[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ap[r] = imgp(4 * bi + r);
+  d4_t acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = d4_t{0.0, 0.0, 0.0, 0.0};
+  if (live) {
+#pragma unroll 1
+    for (int k0 = 0; k0 < 8; k0 += 4) {
+      double2 bv[4][2], av[4][4][2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bv[kk][0] = *reinterpret_cast<const double2*>(bp + 256 * (k0 + kk));
+        bv[kk][1] = *reinterpret_cast<const double2*>(bp + 256 * (k0 + kk) + 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          av[kk][r][0] = *reinterpret_cast<const double2*>(ap[r] + 256 * (k0 + kk));
+          av[kk][r][1] = *reinterpret_cast<const double2*>(ap[r] + 256 * (k0 + kk) + 2);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][r][0].x, bv[kk][0].x, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][r][0].y, bv[kk][0].y, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][r][1].x, bv[kk][1].x, acc[r], 0, 0, 0);
+          acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk][r][1].y, bv[kk][1].y, acc[r], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // half ks finishes row blocks 2 ks, 2 ks + 1; the other two go to the partner wave (w, 1 - ks)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = gf_settle(acc[r]);
+  {
+    double* out = xch + wave * 512 + lane;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const d4_t a = ks == 0 ? acc[2 + q] : acc[q];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(4 * q + g) * 64] = a[g];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  double* Sg = p.S + (size_t)task * N2 * N2;
+  const int col = 16 * cb + lc;
+  const double* xc = Xc + (16 * w + lc) * DP;
+  const double* in = xch + (wave ^ 4) * 512 + lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int r = 2 * ks + q, rb = 4 * bi + r;
+    if (rb < cb || 16 * rb >= N2) continue;   // strictly upper block / past the matrix (wave-uniform)
+    const d4_t a = ks == 0 ? acc[q] : acc[2 + q];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * rb + lq + 4 * g;
+      double k = os * kernel_from_sqdist<KIND>(bk_sqdist(Xr + (16 * r + lq + 4 * g) * DP, xc, D), exptab);
+      if (row == col) k += diag_add;
+      if (row < N2 && col < N2) Sg[(size_t)row * N2 + col] = k - (a[g] + in[(4 * q + g) * 64]);
+    }
+  }
+}
+
+// ---- alpha1 = alpha1' - L11^-T (L21^T alpha2), the scalars, the status ---------------------------------------------------
+// One workgroup of 1024 threads per task.  Nothing on the 16-step chain touches global memory: the rows of L and W_kb of
+// the NEXT step are loaded before this step's barriers (they do not depend on u), u stays in LDS until the end.
+extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(BlockedFitParams p) {
+  __shared__ double part[4][BK_N1];
+  __shared__ double a2s[BK_N1];
+  __shared__ double w[BK_N1];
+  __shared__ double u[BK_N1];
+  __shared__ double wt[256];
+  __shared__ double x[16];
+  const int task = blockIdx.x, tid = threadIdx.x;
+  const int N = p.N;
+  const int n1 = p.n1[task], n2 = p.n2[task], n = n1 + n2;
+  const int i1 = p.info1[task], i2 = p.info2[task];
+  const int info = i1 > 0 ? i1 : (i2 > 0 ? i2 + BK_N1 : 0);
+  if (tid == 0) {
+    p.info[task] = info;
+    if (p.jitter_used) p.jitter_used[task] = p.jit_ladder[task];
+    const double nan = __builtin_nan("");
+    const double q = p.q12[task] + p.q12[2 * p.T + task], ld = p.q12[p.T + task] + p.q12[3 * p.T + task];
+    if (p.quad) p.quad[task] = info ? nan : q;
+    if (p.logdet) p.logdet[task] = info ? nan : ld;
+    if (p.mll) p.mll[task] = info ? nan : (n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0);
+  }
+  if (info || n2 == 0) return;   // (no second block: alpha1' is alpha1)
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * ((N + 15) / 16) * 256;
+  double* al = p.alpha + (size_t)task * N;
+  const int j = tid & 255, quarter = tid >> 8;
+  if (tid < BK_N1) a2s[tid] = tid < n2 ? al[BK_N1 + tid] : 0.0;
+  __syncthreads();
+  {
+    // w = L21^T alpha2: thread (quarter, j) sums its quarter of the rows of column j (rows read coalesced, 16 in flight)
+    const int r0 = quarter * 64;
+    const double* col = Lg + (size_t)(BK_N1 + r0) * N + j;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 1
+    for (int rb = 0; rb < 64; rb += 16) {
+      if (r0 + rb >= n2) break;
+      double cv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cv[q] = r0 + rb + q < n2 ? col[(size_t)(rb + q) * N] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; q += 4) {
+        s0 = __builtin_fma(cv[q], a2s[r0 + rb + q], s0);
+        s1 = __builtin_fma(cv[q + 1], a2s[r0 + rb + q + 1], s1);
+        s2 = __builtin_fma(cv[q + 2], a2s[r0 + rb + q + 2], s2);
+        s3 = __builtin_fma(cv[q + 3], a2s[r0 + rb + q + 3], s3);
+      }
+    }
+    part[quarter][j] = (s0 + s1) + (s2 + s3);
+  }
+  // u = L11^-T w by blocks from the bottom: u_kb = W_kb^T w_kb, then w_j -= L[kb][j]^T u_kb for the columns j left of the block
+  const int nb1 = (n1 + 15) / 16;
+  const bool worker = tid < 256;
+  double lcur[16], wcur = 0.0;
+  auto load_rows = [&](int kb, double* dst, double& wd) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[r] = (tid < 16 * kb && 16 * kb + r < n1) ? Lg[(size_t)(16 * kb + r) * N + tid] : 0.0;
+    wd = Wg[(size_t)kb * 256 + tid];   // W_kb[r = tid / 16][c = tid % 16]
+  };
+  if (worker && nb1 > 0) load_rows(nb1 - 1, lcur, wcur);
+  __syncthreads();
+  if (!worker) return;   // the chain below is four waves' work: the others leave (s_barrier counts the waves still alive)
+  w[tid] = tid < n1 ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.0;
+  for (int kb = nb1 - 1; kb >= 0; --kb) {
+    double lnext[16], wnext = 0.0;
+    if (worker && kb > 0) load_rows(kb - 1, lnext, wnext);
+    __syncthreads();                                        // w complete for block kb
+    if (worker) wt[tid] = wcur * w[16 * kb + (tid >> 4)];   // W[r][c] w_r
+    __syncthreads();
+    if (tid < 16) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += wt[16 * r + tid];
+      x[tid] = s;                                           // u_kb[c] = sum_r W[r][c] w_r
+      u[16 * kb + tid] = s;
+    }
+    __syncthreads();
+    if (tid < 16 * kb) {
+      double s = w[tid];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s = __builtin_fma(-lcur[r], x[r], s);
+      w[tid] = s;
+    }
+    if (kb > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lcur[r] = lnext[r];
+      wcur = wnext;
+    }
+  }
+  __syncthreads();
+  if (tid < n1) al[tid] -= u[tid];
+}
+
+}  // namespace scaml
+
+template __global__ void scaml::gp_blocked_solve_kernel<0, false>(scaml::BlockedFitParams);
+template __global__ void scaml::gp_blocked_solve_kernel<1, false>(scaml::BlockedFitParams);
+template __global__ void scaml::gp_blocked_solve_kernel<0, true>(scaml::BlockedFitParams);
+template __global__ void scaml::gp_blocked_solve_kernel<1, true>(scaml::BlockedFitParams);
+template __global__ void scaml::gp_blocked_syrk_kernel<0>(scaml::BlockedFitParams);
+template __global__ void scaml::gp_blocked_syrk_kernel<1>(scaml::BlockedFitParams);

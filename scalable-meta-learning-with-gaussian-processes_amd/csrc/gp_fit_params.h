@@ -34,4 +34,36 @@ struct FitBlockParams {
   int ldl;                  // leading dimension of L
 };
 
+// Kernel-argument block of the blocked fit's own kernels (csrc/gp_fit_blocked.hip): the caller's arrays, then the workspace.
+struct BlockedFitParams {
+  const double* X;          // (T, N, D)
+  const double* y;          // (T, N)
+  const double* theta;      // (T, D+2)
+  const int32_t* n_points;  // (T) or NULL
+  const double* jitter_in;  // (T) or NULL
+  double* L;                // (T, N, N)
+  double* alpha;            // (T, N)
+  double* quad;
+  double* logdet;
+  double* mll;
+  int32_t* info;
+  double* jitter_used;
+  double* Linv_diag;        // (T, N/16, 16, 16)
+  // workspace (scaml_gp_fit_blocked_workspace_bytes)
+  double* S;                // (T, N2, N2) Schur complement, lower triangle
+  double* Vimg;             // (T, 16 strips, 16 block rows, 64 lanes, 4) blocks of L21^T as the matrix core holds them
+  double* r2;               // (T, N): [N1:] = y2 - K21 alpha1'
+  double* q12;              // [4][T]: quad / logdet of block 1, of block 2
+  double* jit_cur;          // (T) this round's jitter (caller's + ladder)
+  double* jit_ladder;       // (T) the ladder value alone (-> jitter_used)
+  int32_t* n1;              // (T) points in block 1
+  int32_t* n2;              // (T) ... in block 2
+  int32_t* active;          // (T) 0: the task is done, this round leaves it alone
+  int32_t* info1;           // (T) status of block 1
+  int32_t* info2;           // (T) status of block 2
+  int T, N, D;
+  unsigned flags;
+  int round;
+};
+
 }  // namespace scaml

@@ -54,6 +54,8 @@ struct Module {
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipFunction_t tgt_assemble[2] = {nullptr, nullptr};
   hipFunction_t tgt_finish = nullptr;
+  hipFunction_t blk_round = nullptr, blk_finish = nullptr;
+  hipFunction_t blk_solve[2][2] = {}, blk_syrk[2] = {nullptr, nullptr};   // solve: [kind][D <= 8]
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
   hipFunction_t mllgrad_split[2][2][2] = {};   // LDS-DMA staging, [N <= 128 | N <= 256 class][2 | 4 workgroups per task][kind]
   hipError_t load() {
@@ -118,6 +120,19 @@ struct Module {
       if ((e = hipModuleGetFunction(&tgt_assemble[kind], mod, name)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&tgt_finish, mod, "scaml_target_finish_kernel")) != hipSuccess) return e;
+    if ((e = hipModuleGetFunction(&blk_round, mod, "scaml_blocked_round_kernel")) != hipSuccess) return e;
+    if ((e = hipModuleGetFunction(&blk_finish, mod, "scaml_blocked_finish_kernel")) != hipSuccess) return e;
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      for (int sd = 0; sd < 2; ++sd) {
+        snprintf(name, sizeof(name), "_ZN5scaml23gp_blocked_solve_kernelILi%dELb%dEEEvNS_16BlockedFitParamsE", kind, sd);
+        if ((e = hipModuleGetFunction(&blk_solve[kind][sd], mod, name)) != hipSuccess) return e;
+        if ((e = hipFuncSetAttribute((const void*)blk_solve[kind][sd], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+      }
+      snprintf(name, sizeof(name), "_ZN5scaml22gp_blocked_syrk_kernelILi%dEEEvNS_16BlockedFitParamsE", kind);
+      if ((e = hipModuleGetFunction(&blk_syrk[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)blk_syrk[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    }
     for (int cls = 0; cls < 2; ++cls) {
       for (int sp = 0; sp < 2; ++sp) {
         for (int kind = 0; kind < 2; ++kind) {
@@ -221,6 +236,113 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
   if (T == 0) return SCAML_OK;
   scaml::FitParams p{X, y, theta, n_points, jitter_in, nullptr, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag, T, N, D, flags};
   return fit_common(p, kind, stream);
+}
+
+// ---- (3b) blocked fit, 256 < N <= 512 ---------------------------------------------------------------------
+int scaml_fit_blocked_max_n(void) { return 512; }
+
+static size_t blocked_solve_lds_bytes(int D) {
+  const size_t dp = D <= 8 ? 9 : (size_t)(D | 1);   // (D <= 8: staged zero-padded to 8 dimensions)
+  return (3 * 16 * 258 + 256 * dp + 64 * dp + 256 + 64 + (D <= 8 ? 8 : (size_t)D) + 1) * sizeof(double);
+}
+
+int scaml_fit_blocked_max_d(void) {
+  static int dmax = 0;
+  if (!dmax) {
+    int d = 1;
+    while (blocked_solve_lds_bytes(d + 1) <= 160 * 1024) ++d;
+    const int dfit = scaml_fit_max_d(256);
+    dmax = d < dfit ? d : dfit;
+  }
+  return dmax;
+}
+
+namespace {
+struct BlockedLayout {
+  size_t S, Vimg, r2, q12, jit_cur, jit_ladder, n1, n2, active, info1, info2, total;
+};
+BlockedLayout blocked_layout(int T, int N) {
+  const size_t n2 = (size_t)(N - 256), t = (size_t)T, tp = (t + 1) & ~(size_t)1;   // (int arrays: 8-byte multiples)
+  BlockedLayout l{};
+  size_t o = 0;
+  l.S = o; o += t * n2 * n2 * 8;
+  l.Vimg = o; o += t * 256 * 256 * 8;
+  l.r2 = o; o += t * (size_t)N * 8;
+  l.q12 = o; o += 4 * t * 8;
+  l.jit_cur = o; o += t * 8;
+  l.jit_ladder = o; o += t * 8;
+  l.n1 = o; o += tp * 4;
+  l.n2 = o; o += tp * 4;
+  l.active = o; o += tp * 4;
+  l.info1 = o; o += tp * 4;
+  l.info2 = o; o += tp * 4;
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+long long scaml_gp_fit_blocked_workspace_bytes(int T, int N) {
+  if (T < 0 || N <= 256 || N > 512) return 0;
+  return (long long)blocked_layout(T, N).total;
+}
+
+int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* theta,
+                             const int32_t* n_points, const double* jitter_in,
+                             int T, int N, int D, int kind,
+                             double* L, double* alpha, double* quad, double* logdet, double* mll,
+                             int32_t* info, double* jitter_used, double* Linv_diag, unsigned flags,
+                             void* workspace, long long workspace_bytes, void* stream) {
+  if (T < 0 || N < 1 || D < 1) return SCAML_E_BADARG;
+  if (!X || !y || !theta || !info || !L || !alpha || !Linv_diag) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (N <= scaml_fit_max_n() || N > scaml_fit_blocked_max_n() || (N & 15)) return SCAML_E_TOOLARGE;
+  if (D > scaml_fit_blocked_max_d()) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  const BlockedLayout lay = blocked_layout(T, N);
+  if (!workspace || workspace_bytes < (long long)lay.total || ((uintptr_t)workspace & 15)) return SCAML_E_BADARG;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  char* ws = (char*)workspace;
+  const int N1 = 256, N2 = N - N1, NBT = N / 16;
+  scaml::BlockedFitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag,
+                            (double*)(ws + lay.S), (double*)(ws + lay.Vimg), (double*)(ws + lay.r2), (double*)(ws + lay.q12), (double*)(ws + lay.jit_cur),
+                            (double*)(ws + lay.jit_ladder), (int32_t*)(ws + lay.n1), (int32_t*)(ws + lay.n2), (int32_t*)(ws + lay.active),
+                            (int32_t*)(ws + lay.info1), (int32_t*)(ws + lay.info2), T, N, D, flags, 0};
+  const unsigned fl = SCAML_FIT_STORE_L | SCAML_FIT_NO_RETRY | (flags & SCAML_FIT_ZERO_UPPER);
+  scaml::FitParams f1{X, y, theta, p.n1, p.jit_cur, nullptr, L, alpha, p.q12, p.q12 + T, nullptr, p.info1, nullptr, Linv_diag, T, N1, D, fl};
+  const scaml::FitBlockParams b1{(long long)N * D, N, (long long)N * N, (long long)NBT * 256, p.active, N};
+  scaml::FitParams f2{nullptr, p.r2 + N1, nullptr, p.n2, nullptr, p.S, L + (size_t)N1 * N + N1, alpha + N1, p.q12 + 2 * (size_t)T, p.q12 + 3 * (size_t)T,
+                      nullptr, p.info2, nullptr, Linv_diag + (size_t)(N1 / 16) * 256, T, N2, 1, fl};
+  const scaml::FitBlockParams b2{0, N, (long long)N * N, (long long)NBT * 256, p.active, N};
+  const size_t lds_solve = blocked_solve_lds_bytes(D);
+  const size_t lds_syrk = (size_t)(8 * 512 + 128 * (D | 1) + 64 + D + 1) * sizeof(double);
+  const int nt = (N2 + 63) / 64;
+  const int t8 = (T + 7) / 8 * 8;   // tasks ride on grid.x, dealt to the XCDs (bk_task_part)
+  const int rounds = (flags & SCAML_FIT_NO_RETRY) ? 1 : 4;
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  hipStream_t st = (hipStream_t)stream;
+  for (int r = 0; r < rounds; ++r) {
+    p.round = r;
+    if ((e = hipModuleLaunchKernel(m.blk_round, (unsigned)((T + 255) / 256), 1, 1, 256, 1, 1, 0, st, nullptr, config)) != hipSuccess) {
+      set_error("hipModuleLaunchKernel(blocked_round)", e); return SCAML_E_LAUNCH;
+    }
+    int rc = fit_common(f1, kind, stream, &b1);
+    if (rc != SCAML_OK) return rc;
+    if ((e = hipModuleLaunchKernel(m.blk_solve[kind][D <= 8 ? 1 : 0], (unsigned)(t8 * nt), 1, 1, 256, 1, 1, (unsigned)lds_solve, st, nullptr, config)) != hipSuccess) {
+      set_error("hipModuleLaunchKernel(gp_blocked_solve)", e); return SCAML_E_LAUNCH;
+    }
+    if ((e = hipModuleLaunchKernel(m.blk_syrk[kind], (unsigned)(t8 * (nt * (nt + 1) / 2)), 1, 1, 512, 1, 1, (unsigned)lds_syrk, st, nullptr, config)) != hipSuccess) {
+      set_error("hipModuleLaunchKernel(gp_blocked_syrk)", e); return SCAML_E_LAUNCH;
+    }
+    rc = fit_common(f2, SCAML_KIND_RBF, stream, &b2);
+    if (rc != SCAML_OK) return rc;
+  }
+  if ((e = hipModuleLaunchKernel(m.blk_finish, (unsigned)T, 1, 1, 1024, 1, 1, 0, st, nullptr, config)) != hipSuccess) {
+    set_error("hipModuleLaunchKernel(blocked_finish)", e); return SCAML_E_LAUNCH;
+  }
+  return SCAML_OK;
 }
 
 // ---- (2) batched jittered Cholesky of given matrices ------------------------------------------------

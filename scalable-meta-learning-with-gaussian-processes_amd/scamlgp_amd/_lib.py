@@ -55,6 +55,20 @@ def _load() -> ctypes.CDLL:
     lib.scaml_fit_max_n.argtypes = []
     lib.scaml_fit_max_d.restype = c_int
     lib.scaml_fit_max_d.argtypes = [c_int]
+    lib.scaml_fit_blocked_max_n.restype = c_int
+    lib.scaml_fit_blocked_max_n.argtypes = []
+    lib.scaml_fit_blocked_max_d.restype = c_int
+    lib.scaml_fit_blocked_max_d.argtypes = []
+    lib.scaml_gp_fit_blocked_workspace_bytes.restype = ctypes.c_longlong
+    lib.scaml_gp_fit_blocked_workspace_bytes.argtypes = [c_int, c_int]
+    lib.scaml_gp_fit_blocked_f64.restype = c_int
+    lib.scaml_gp_fit_blocked_f64.argtypes = [
+        _dp, _dp, _dp, _dp, _dp,  # X, y, theta, n_points, jitter_in
+        c_int, c_int, c_int, c_int,  # T, N, D, kind
+        _dp, _dp, _dp, _dp, _dp,  # L, alpha, quad, logdet, mll
+        _dp, _dp, _dp, ctypes.c_uint,  # info, jitter_used, Linv_diag, flags
+        _dp, ctypes.c_longlong, _dp,  # workspace, workspace_bytes, stream
+    ]
     lib.scaml_gp_fit_fused_f64.restype = c_int
     lib.scaml_gp_fit_fused_f64.argtypes = [
         _dp, _dp, _dp, _dp, _dp,  # X, y, theta, n_points, jitter_in
@@ -117,6 +131,10 @@ EXPORTED_SYMBOLS = (
     "scaml_fit_max_n",
     "scaml_fit_max_d",
     "scaml_gp_fit_fused_f64",
+    "scaml_fit_blocked_max_n",
+    "scaml_fit_blocked_max_d",
+    "scaml_gp_fit_blocked_workspace_bytes",
+    "scaml_gp_fit_blocked_f64",
     "scaml_kernel_matrix_f64",
     "scaml_potrf_batched_f64",
     "scaml_posterior_max_n",

@@ -78,6 +78,8 @@ def gp_fit_fused(
     if N > _lib.lib.scaml_fit_max_n():
         if out is not None:
             raise ValueError("out= is not supported beyond scaml_fit_max_n()")
+        if N <= _lib.lib.scaml_fit_blocked_max_n() and N % 16 == 0 and D <= _lib.lib.scaml_fit_blocked_max_d() and not _FORCE_COMPOSED_TWO_BLOCK:
+            return _gp_fit_blocked(X, y, theta, kind, n_points, jitter, zero_upper, retry)
         return _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry)
     dev = X.device
     with torch.cuda.device(dev):
@@ -117,6 +119,35 @@ def gp_fit_fused(
             _ptr(info), _ptr(jit_used), _ptr(linv), flags, _stream_handle(),
         )
     _lib.check_rc(rc, "scaml_gp_fit_fused_f64")
+    return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used, Linv_diag=linv)
+
+
+_FORCE_COMPOSED_TWO_BLOCK = False   # tests / A-B timing: route 256 < N <= 512 through _gp_fit_two_block
+
+
+def _gp_fit_blocked(X, y, theta, kind, n_points, jitter, zero_upper, retry) -> Dict[str, torch.Tensor]:
+    """Fused fit for scaml_fit_max_n() < N <= scaml_fit_blocked_max_n() (the N = 512 source tasks of BASELINE
+    configs[4]): ``scaml_gp_fit_blocked_f64`` -- a 2 x 2 block factorisation enqueued as one sequence of the
+    library's launches (csrc/gp_fit_blocked.hip), jitter ladder included, without a host synchronisation or a
+    framework op in between.  L and Linv_diag are always produced (the later launches read them)."""
+    T, N, D = X.shape
+    dev = X.device
+    with torch.cuda.device(dev):
+        # ragged stacks: rows past n_t are never written but READ by the strip solve -> zeros
+        L = (torch.zeros if n_points is not None else torch.empty)((T, N, N), dtype=torch.float64, device=dev)
+        alpha = (torch.zeros if n_points is not None else torch.empty)((T, N), dtype=torch.float64, device=dev)
+        quad, logdet, mll, jit_used = (torch.empty((T,), dtype=torch.float64, device=dev) for _ in range(4))
+        info = torch.empty((T,), dtype=torch.int32, device=dev)
+        linv = torch.empty((T, N // 16, 16, 16), dtype=torch.float64, device=dev)
+        nbytes = int(_lib.lib.scaml_gp_fit_blocked_workspace_bytes(T, N))
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+        flags = _lib.FIT_STORE_L | (_lib.FIT_ZERO_UPPER if zero_upper else 0) | (0 if retry else _lib.FIT_NO_RETRY)
+        rc = _lib.lib.scaml_gp_fit_blocked_f64(
+            _ptr(X), _ptr(y), _ptr(theta), _ptr(n_points), _ptr(jitter), T, N, D, int(kind),
+            _ptr(L), _ptr(alpha), _ptr(quad), _ptr(logdet), _ptr(mll), _ptr(info), _ptr(jit_used), _ptr(linv), flags,
+            _ptr(ws), nbytes, _stream_handle())
+        ws.record_stream(torch.cuda.current_stream(dev))
+    _lib.check_rc(rc, "scaml_gp_fit_blocked_f64")
     return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info, jitter=jit_used, Linv_diag=linv)
 
 
