@@ -20,6 +20,14 @@
 
 namespace scaml {
 
+#ifdef BK_STAMPS   // developer build: cycle stamps of (part 0, wave 0) into the unused head of the task's r2 row (tools/dev_blk_stamps.py)
+#define BK_STAMP(slot) do { if (stamp_on) p.r2[(size_t)task * p.N + (slot)] = (double)(__builtin_amdgcn_s_memtime() - stamp_t0); } while (0)
+#define BK_STAMP_INIT(cond) const bool stamp_on = (cond); const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime()
+#else
+#define BK_STAMP(slot) do { } while (0)
+#define BK_STAMP_INIT(cond) do { } while (0)
+#endif
+
 constexpr int BK_N1 = 256;   // block 1: what the single-launch kernel takes
 constexpr int BK_NB1 = 16;
 
@@ -158,6 +166,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
     }
   };
 
+  BK_STAMP_INIT(sg == 0 && tid == 0);
   dma_step(0);
   dma_step(1);
   exp2_table_init(exptab, tid);
@@ -185,6 +194,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
     for (int d = 0; d < 8; ++d) xcr[d] = xc[d];
   }
   double macc = 0.0;                        // lane's share of K21 alpha1' at its point
+  BK_STAMP(0);
   for (int kb = 0; kb < BK_NB1; ++kb) {
     if (kb + 2 < BK_NB1) dma_step(kb + 2);  // into the buffer step kb - 1 read from: everybody is past the barrier that ended it
     double kv[4];
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
       kv[g] = (row < n1 && col_ok) ? k : 0.0;
       macc = __builtin_fma(kv[g], a1s[row], macc);
     }
+    BK_STAMP(1 + 4 * kb);   // kernel values done
     GF_DRAIN();   // (the previous step's closing product may still be reading ACC)
     gf_acc_set(kv[0], kv[1], kv[2], kv[3]);
     const double* pa = buf + (kb % 3) * BUF + lc * PA + lq;   // A operand: L[16 kb + lc][16 j + lq + 4 m]
@@ -216,11 +227,14 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
       BK_STEP_CASE(15)
       default: break;
     }
+    BK_STAMP(2 + 4 * kb);   // chain issued
     // this wave's pieces of row block kb + 1 have landed; those of kb + 2 (4 or 8 instructions, issued above) may be in flight
     if (kb + 2 >= BK_NB1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (kb + 2 >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    BK_STAMP(3 + 4 * kb);   // staged rows landed
     __syncthreads();
+    BK_STAMP(4 + 4 * kb);   // barrier passed
   }
   GF_DRAIN();
   // the strip goes to memory as rows of L21 (and, on request, zeros into the mirrored block of the upper triangle)
@@ -250,6 +264,8 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   if (zero_upper && urow) {
     for (int r = lq; r < BK_N1; r += 4) urow[(size_t)r * N] = 0.0;   // the mirrored block of the upper triangle: 128-byte row pieces
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BK_STAMP(70);   // strip stored
   macc = sum_lane_groups(macc);
   if (lq == 0 && in_matrix) p.r2[(size_t)task * N + BK_N1 + colpt] = col_ok ? p.y[(size_t)task * N + BK_N1 + colpt] - macc : 0.0;
 }
@@ -366,15 +382,41 @@ __global__ __launch_bounds__(512, 4) void gp_blocked_syrk_kernel(BlockedFitParam
 }
 
 // ---- alpha1 = alpha1' - L11^-T (L21^T alpha2), the scalars, the status ---------------------------------------------------
-// One workgroup of 1024 threads per task.  Nothing on the 16-step chain touches global memory: the rows of L and W_kb of
-// the NEXT step are loaded before this step's barriers (they do not depend on u), u stays in LDS until the end.
+// One workgroup of 1024 threads per task; thread (q, j) = (tid / 256, tid % 256).  u = L11^-T w runs by blocks from the
+// bottom: u_kb = W_kb^T w_kb, then w_j -= sum_r L[16 kb + r][j] u_kb[r] for the columns j left of the block.  Nothing on
+// that 16-step chain waits for global memory: all W_kb sit in LDS, thread (q, j) holds rows 4 q .. 4 q + 3 of the block
+// rows in a ring of registers filled eight steps ahead, every wave forms u_kb for itself (no hand-over through LDS), and
+// the partial sums of the four quarters meet in LDS atomics: one barrier per step.  (n2 > 0 here, so block 1 is full.)
+template <int KB>
+__device__ __forceinline__ void bk_finish_load(double (&dst)[4], const double* Lg, int N, int q, int j) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[i] = j < 16 * KB ? Lg[(size_t)(16 * KB + 4 * q + i) * N + j] : 0.0;
+}
+
+template <int KB>
+__device__ __forceinline__ void bk_finish_step(const double (&lrow)[4], const double* Wl, double* w, double* u, int q, int j, int lane) {
+  __syncthreads();   // w_kb is complete (the previous step's atomics have landed)
+  // u_kb[c] on lane (c = lane % 16, any lane / 16): every wave computes all of it
+  const int c = lane & 15, rg = lane >> 4;
+  double xv = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xv = __builtin_fma(Wl[KB * 256 + (4 * rg + i) * 16 + c], w[16 * KB + 4 * rg + i], xv);
+  xv = sum_lane_groups(xv);
+  if (q == 0 && j < 16) u[16 * KB + j] = xv;
+  if constexpr (KB > 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s = __builtin_fma(lrow[i], readlane_f64(xv, 4 * q + i), s);
+    if (j < 16 * KB) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(w + j), -s);
+  }
+}
+
 extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(BlockedFitParams p) {
+  __shared__ double Wl[BK_NB1 * 256];
   __shared__ double part[4][BK_N1];
   __shared__ double a2s[BK_N1];
   __shared__ double w[BK_N1];
   __shared__ double u[BK_N1];
-  __shared__ double wt[256];
-  __shared__ double x[16];
   const int task = blockIdx.x, tid = threadIdx.x;
   const int N = p.N;
   const int n1 = p.n1[task], n2 = p.n2[task], n = n1 + n2;
@@ -390,15 +432,26 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
     if (p.mll) p.mll[task] = info ? nan : (n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0);
   }
   if (info || n2 == 0) return;   // (no second block: alpha1' is alpha1)
+  BK_STAMP_INIT(tid == 0);
   const double* Lg = p.L + (size_t)task * N * N;
   const double* Wg = p.Linv_diag + (size_t)task * ((N + 15) / 16) * 256;
   double* al = p.alpha + (size_t)task * N;
-  const int j = tid & 255, quarter = tid >> 8;
+  const int j = tid & 255, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+  // the ring's first eight block rows (15 .. 8) and every W_kb start their way now
+  double ring[8][4];
+  bk_finish_load<15>(ring[7], Lg, N, q, j); bk_finish_load<14>(ring[6], Lg, N, q, j);
+  bk_finish_load<13>(ring[5], Lg, N, q, j); bk_finish_load<12>(ring[4], Lg, N, q, j);
+  bk_finish_load<11>(ring[3], Lg, N, q, j); bk_finish_load<10>(ring[2], Lg, N, q, j);
+  bk_finish_load<9>(ring[1], Lg, N, q, j); bk_finish_load<8>(ring[0], Lg, N, q, j);
+  double wl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wl[i] = Wg[tid + 1024 * i];
   if (tid < BK_N1) a2s[tid] = tid < n2 ? al[BK_N1 + tid] : 0.0;
   __syncthreads();
   {
-    // w = L21^T alpha2: thread (quarter, j) sums its quarter of the rows of column j (rows read coalesced, 16 in flight)
-    const int r0 = quarter * 64;
+    // w = L21^T alpha2: thread (q, j) sums its quarter of the rows of column j (rows read coalesced, 16 in flight)
+    const int r0 = q * 64;
     const double* col = Lg + (size_t)(BK_N1 + r0) * N + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 1
@@ -406,58 +459,37 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
       if (r0 + rb >= n2) break;
       double cv[16];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) cv[q] = r0 + rb + q < n2 ? col[(size_t)(rb + q) * N] : 0.0;
+      for (int k = 0; k < 16; ++k) cv[k] = r0 + rb + k < n2 ? col[(size_t)(rb + k) * N] : 0.0;
 #pragma unroll
-      for (int q = 0; q < 16; q += 4) {
-        s0 = __builtin_fma(cv[q], a2s[r0 + rb + q], s0);
-        s1 = __builtin_fma(cv[q + 1], a2s[r0 + rb + q + 1], s1);
-        s2 = __builtin_fma(cv[q + 2], a2s[r0 + rb + q + 2], s2);
-        s3 = __builtin_fma(cv[q + 3], a2s[r0 + rb + q + 3], s3);
+      for (int k = 0; k < 16; k += 4) {
+        s0 = __builtin_fma(cv[k], a2s[r0 + rb + k], s0);
+        s1 = __builtin_fma(cv[k + 1], a2s[r0 + rb + k + 1], s1);
+        s2 = __builtin_fma(cv[k + 2], a2s[r0 + rb + k + 2], s2);
+        s3 = __builtin_fma(cv[k + 3], a2s[r0 + rb + k + 3], s3);
       }
     }
-    part[quarter][j] = (s0 + s1) + (s2 + s3);
+    part[q][j] = (s0 + s1) + (s2 + s3);
   }
-  // u = L11^-T w by blocks from the bottom: u_kb = W_kb^T w_kb, then w_j -= L[kb][j]^T u_kb for the columns j left of the block
-  const int nb1 = (n1 + 15) / 16;
-  const bool worker = tid < 256;
-  double lcur[16], wcur = 0.0;
-  auto load_rows = [&](int kb, double* dst, double& wd) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dst[r] = (tid < 16 * kb && 16 * kb + r < n1) ? Lg[(size_t)(16 * kb + r) * N + tid] : 0.0;
-    wd = Wg[(size_t)kb * 256 + tid];   // W_kb[r = tid / 16][c = tid % 16]
-  };
-  if (worker && nb1 > 0) load_rows(nb1 - 1, lcur, wcur);
+  for (int i = 0; i < 4; ++i) Wl[tid + 1024 * i] = wl[i];
   __syncthreads();
-  if (!worker) return;   // the chain below is four waves' work: the others leave (s_barrier counts the waves still alive)
-  w[tid] = tid < n1 ? (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]) : 0.0;
-  for (int kb = nb1 - 1; kb >= 0; --kb) {
-    double lnext[16], wnext = 0.0;
-    if (worker && kb > 0) load_rows(kb - 1, lnext, wnext);
-    __syncthreads();                                        // w complete for block kb
-    if (worker) wt[tid] = wcur * w[16 * kb + (tid >> 4)];   // W[r][c] w_r
-    __syncthreads();
-    if (tid < 16) {
-      double s = 0.0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += wt[16 * r + tid];
-      x[tid] = s;                                           // u_kb[c] = sum_r W[r][c] w_r
-      u[16 * kb + tid] = s;
-    }
-    __syncthreads();
-    if (tid < 16 * kb) {
-      double s = w[tid];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s = __builtin_fma(-lcur[r], x[r], s);
-      w[tid] = s;
-    }
-    if (kb > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lcur[r] = lnext[r];
-      wcur = wnext;
-    }
-  }
+  if (tid < BK_N1) w[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  BK_STAMP(100);   // mat-vec done
+  bk_finish_step<15>(ring[7], Wl, w, u, q, j, lane); bk_finish_load<7>(ring[7], Lg, N, q, j);
+  bk_finish_step<14>(ring[6], Wl, w, u, q, j, lane); bk_finish_load<6>(ring[6], Lg, N, q, j);
+  bk_finish_step<13>(ring[5], Wl, w, u, q, j, lane); bk_finish_load<5>(ring[5], Lg, N, q, j);
+  bk_finish_step<12>(ring[4], Wl, w, u, q, j, lane); bk_finish_load<4>(ring[4], Lg, N, q, j);
+  bk_finish_step<11>(ring[3], Wl, w, u, q, j, lane); bk_finish_load<3>(ring[3], Lg, N, q, j);
+  bk_finish_step<10>(ring[2], Wl, w, u, q, j, lane); bk_finish_load<2>(ring[2], Lg, N, q, j);
+  bk_finish_step<9>(ring[1], Wl, w, u, q, j, lane); bk_finish_load<1>(ring[1], Lg, N, q, j);
+  bk_finish_step<8>(ring[0], Wl, w, u, q, j, lane);
+  bk_finish_step<7>(ring[7], Wl, w, u, q, j, lane); bk_finish_step<6>(ring[6], Wl, w, u, q, j, lane);
+  bk_finish_step<5>(ring[5], Wl, w, u, q, j, lane); bk_finish_step<4>(ring[4], Wl, w, u, q, j, lane);
+  bk_finish_step<3>(ring[3], Wl, w, u, q, j, lane); bk_finish_step<2>(ring[2], Wl, w, u, q, j, lane);
+  bk_finish_step<1>(ring[1], Wl, w, u, q, j, lane); bk_finish_step<0>(ring[0], Wl, w, u, q, j, lane);
   __syncthreads();
-  if (tid < n1) al[tid] -= u[tid];
+  BK_STAMP(101);   // chain done
+  if (tid < BK_N1) al[tid] -= u[tid];
 }
 
 }  // namespace scaml
