@@ -2,10 +2,11 @@
 // device (gfx950): no host synchronisation, no framework ops between the launches.
 //
 //        [K11 K12]   [L11      ] [L11^T L21^T]      L11  = fused fit of block 1, in place     (gp_fit_blocked_kernel, 1 CU / task)
-//        [K21 K22] = [L21   L22] [      L22^T]      L21^T = L11^-1 K12, r2 = y2 - K21 alpha1'  (gp_blocked_solve_kernel, 4 CUs / task)
+//        [K21 K22] = [L21   L22] [      L22^T]      L21^T = L11^-1 K12, r2 = y2 - L21 v1       (gp_blocked_solve_kernel, 4 CUs / task)
 //                                                   S    = K22 + (noise + jitter) I - L21 L21^T (gp_blocked_syrk_kernel, 10 CUs / task)
 //                                                   L22  = chol(S), alpha2 = S^-1 r2, in place  (gp_fit_blocked_kernel on S)
-//                                                   alpha1 = alpha1' - L11^-T (L21^T alpha2), MLL (gp_blocked_finish_kernel)
+//                                                   alpha1 = L11^-T (v1 - L21^T alpha2), MLL    (gp_blocked_finish_kernel)
+// (v1 = L11^-1 y1: the first fit stops after its forward substitution, FIT_FORWARD_ONLY)
 //
 // The reference fits source GPs of up to 512 points (scamlgp/benchmarking/configurations/
 // hartmann6_ablation_num_points_per_task.py:17-18) with gpytorch's ExactGP (kernel matrix -> psd_safe_cholesky ->
@@ -78,7 +79,7 @@ __device__ __forceinline__ double bk_sqdist(const double* a, const double* b, in
   return s;
 }
 
-// ---- L21^T = L11^-1 K12 by column strips, r2 = y2 - K21 alpha1' --------------------------------------------------------
+// ---- L21^T = L11^-1 K12 by column strips, r2 = y2 - L21 v1 -------------------------------------------------------------
 // One wave owns one strip (16 points of block 2): its 16 blocks Z_0..Z_15 live in hand-managed AGPRs in the MFMA C/D
 // layout = the B-operand layout (csrc/gf_tiles.hpp), so a finished block feeds the next products from the registers it
 // was computed in.  The four waves of a workgroup advance in lockstep over the block rows of L11; row block kb (with
@@ -97,10 +98,13 @@ __device__ __forceinline__ void bk_solve_step(const double* pa) {
 // global store is 1 KB of one row (the direct store would scatter 32-byte pieces over 16 rows 4 KB apart).
 constexpr int BK_TP = 132;   // LDS pitch of a transposed half row (128 columns)
 template <int J, int J1>
-__device__ __forceinline__ void bk_stage_strip(double* tr, double* img, bool col_ok, int lc, int lq) {
+__device__ __forceinline__ void bk_stage_strip(double* tr, double* img, const double* v1s, double& macc, bool col_ok, int lc, int lq) {
   // tr[lc][16 (J mod 8) + lq + 4 g] = L21[16 c + lc][16 J + lq + 4 g] = Z_J[lq + 4 g][lc]
   d4_t z = GfTile<gf_slot<BK_NB1, false>(J)>::get();
   if (!col_ok) z = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) macc = __builtin_fma(z[g], v1s[16 * J + lq + 4 * g], macc);   // (L21 v1)[16 c + lc], this lane's rows
+  asm volatile("" : "+v"(macc));   // (evaluate now: left alone, hipcc keeps all 64 values of the strip alive and sums at the very end)
   if (img) {   // the block as the matrix core holds it (lane-major, 32 bytes per lane)
     double2* q = reinterpret_cast<double2*>(img + J * 256);
     q[0] = double2{z[0], z[1]};
@@ -109,7 +113,7 @@ __device__ __forceinline__ void bk_stage_strip(double* tr, double* img, bool col
   double* t = tr + lc * BK_TP + 16 * (J & 7) + lq;
 #pragma unroll
   for (int g = 0; g < 4; ++g) t[4 * g] = z[g];
-  if constexpr (J + 1 < J1) bk_stage_strip<J + 1, J1>(tr, img, col_ok, lc, lq);
+  if constexpr (J + 1 < J1) bk_stage_strip<J + 1, J1>(tr, img, v1s, macc, col_ok, lc, lq);
 }
 
 #define BK_STEP_CASE(K) case K: bk_solve_step<K>(pa); break;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   double* buf = lds;                     // [3][BUF]: row blocks of L11, two steps ahead
   double* X1s = buf + 3 * BUF;           // [NP][DP] block-1 points / lengthscale
   double* X2s = X1s + NP * DP;           // [64][DP] this workgroup's block-2 points / lengthscale
-  double* a1s = X2s + 64 * DP;           // [NP] alpha1'
+  double* a1s = X2s + 64 * DP;           // [NP] v1 = L11^-1 y1
   double* exptab = a1s + NP;             // [64]
   double* invl = exptab + 64;            // [DS]
 
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
 #pragma unroll
     for (int d = 0; d < 8; ++d) xcr[d] = xc[d];
   }
-  double macc = 0.0;                        // lane's share of K21 alpha1' at its point
+  double macc = 0.0;                        // lane's share of (L21 v1) at its point
   BK_STAMP(0);
   for (int kb = 0; kb < BK_NB1; ++kb) {
     if (kb + 2 < BK_NB1) dma_step(kb + 2);  // into the buffer step kb - 1 read from: everybody is past the barrier that ended it
@@ -215,7 +219,6 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
       }
       const double k = os * kernel_from_sqdist<KIND>(d2, exptab);
       kv[g] = (row < n1 && col_ok) ? k : 0.0;
-      macc = __builtin_fma(kv[g], a1s[row], macc);
     }
     BK_STAMP(1 + 4 * kb);   // kernel values done
     GF_DRAIN();   // (the previous step's closing product may still be reading ACC)
@@ -248,8 +251,8 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   const bool strip_in = 16 * c < N2;        // (N2 is a multiple of 16: a strip is inside the matrix or not at all)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (h == 0) bk_stage_strip<0, 8>(tr, img, col_ok, lc, lq);
-    else bk_stage_strip<8, 16>(tr, img, col_ok, lc, lq);
+    if (h == 0) bk_stage_strip<0, 8>(tr, img, a1s, macc, col_ok, lc, lq);
+    else bk_stage_strip<8, 16>(tr, img, a1s, macc, col_ok, lc, lq);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (strip_in) {
@@ -381,12 +384,13 @@ __global__ __launch_bounds__(512, 4) void gp_blocked_syrk_kernel(BlockedFitParam
   }
 }
 
-// ---- alpha1 = alpha1' - L11^-T (L21^T alpha2), the scalars, the status ---------------------------------------------------
+// ---- alpha1 = L11^-T (v1 - L21^T alpha2), the scalars, the status ---------------------------------------------------
 // One workgroup of 1024 threads per task; thread (q, j) = (tid / 256, tid % 256).  u = L11^-T w runs by blocks from the
 // bottom: u_kb = W_kb^T w_kb, then w_j -= sum_r L[16 kb + r][j] u_kb[r] for the columns j left of the block.  Nothing on
 // that 16-step chain waits for global memory: all W_kb sit in LDS, thread (q, j) holds rows 4 q .. 4 q + 3 of the block
 // rows in a ring of registers filled eight steps ahead, every wave forms u_kb for itself (no hand-over through LDS), and
-// the partial sums of the four quarters meet in LDS atomics: one barrier per step.  (n2 > 0 here, so block 1 is full.)
+// the partial sums of the four quarters meet in LDS atomics: one barrier per step.  (A ragged block 1 rides on the identity
+// padding of W_kb and on the zero rows of L the caller provides, include/scaml_gp.h.)
 template <int KB>
 __device__ __forceinline__ void bk_finish_load(double (&dst)[4], const double* Lg, int N, int q, int j) {
 #pragma unroll
@@ -431,7 +435,7 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
     if (p.logdet) p.logdet[task] = info ? nan : ld;
     if (p.mll) p.mll[task] = info ? nan : (n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0);
   }
-  if (info || n2 == 0) return;   // (no second block: alpha1' is alpha1)
+  if (info) return;
   BK_STAMP_INIT(tid == 0);
   const double* Lg = p.L + (size_t)task * N * N;
   const double* Wg = p.Linv_diag + (size_t)task * ((N + 15) / 16) * 256;
@@ -473,7 +477,7 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
 #pragma unroll
   for (int i = 0; i < 4; ++i) Wl[tid + 1024 * i] = wl[i];
   __syncthreads();
-  if (tid < BK_N1) w[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+  if (tid < BK_N1) w[tid] = (tid < n1 ? al[tid] : 0.0) - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));   // v1 - L21^T alpha2
   BK_STAMP(100);   // mat-vec done
   bk_finish_step<15>(ring[7], Wl, w, u, q, j, lane); bk_finish_load<7>(ring[7], Lg, N, q, j);
   bk_finish_step<14>(ring[6], Wl, w, u, q, j, lane); bk_finish_load<6>(ring[6], Lg, N, q, j);
@@ -489,7 +493,7 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
   bk_finish_step<1>(ring[1], Wl, w, u, q, j, lane); bk_finish_step<0>(ring[0], Wl, w, u, q, j, lane);
   __syncthreads();
   BK_STAMP(101);   // chain done
-  if (tid < BK_N1) al[tid] -= u[tid];
+  if (tid < n1) al[tid] = u[tid];
 }
 
 }  // namespace scaml

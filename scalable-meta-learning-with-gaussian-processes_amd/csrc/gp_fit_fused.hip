@@ -975,7 +975,16 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
       for (int e = tid; e < nbn * 256; e += NTHREADS)   // W[r][c] of block b = WAll[b][c][r] (kept transposed)
         Wg[e] = WAll[(e >> 8) * 16 * PP + (e & 15) * PP + ((e >> 4) & 15)];
     }
-    if (p.alpha) {
+    bool want_tail = p.alpha != nullptr;
+    if constexpr (BLK) {
+      // first block of a blocked fit: the caller continues from v = L^-1 y (the back-substitution runs once, over both
+      // blocks, in gp_blocked_finish_kernel)
+      if (want_tail && (p.flags & FIT_FORWARD_ONLY)) {
+        for (int r = tid; r < n; r += NTHREADS) p.alpha[(size_t)task * b.sy((size_t)N) + r] = vv[r];
+        want_tail = false;
+      }
+    }
+    if (want_tail) {
       // alpha = L^-T v by blocks from the bottom: alpha_k = W_k^T w_k, w_j -= L_kj^T alpha_k for j < k.  The
       // dependency chain runs through the tiles next to the diagonal, w_{k-1} <- alpha_k <- w_k, so ONE wave
       // (the panel wave) walks it alone, out of LDS and registers, on the matrix core:

@@ -23,6 +23,8 @@ struct FitParams {
   unsigned flags;
 };
 
+constexpr unsigned FIT_FORWARD_ONLY = 0x100u;   // gp_fit_blocked_kernel only (not part of the C ABI): `alpha` receives v = L^-1 y
+
 // Second argument of gp_fit_blocked_kernel: the same fit run IN PLACE on a diagonal block of a larger task
 // (csrc/gp_fit_blocked.hip).  A plain fit has ldl = N, stride_x = N D, stride_y = N, stride_L = N N, stride_W = ceil(N/16) 256.
 struct FitBlockParams {

@@ -310,7 +310,7 @@ int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* the
                             (double*)(ws + lay.jit_ladder), (int32_t*)(ws + lay.n1), (int32_t*)(ws + lay.n2), (int32_t*)(ws + lay.active),
                             (int32_t*)(ws + lay.info1), (int32_t*)(ws + lay.info2), T, N, D, flags, 0};
   const unsigned fl = SCAML_FIT_STORE_L | SCAML_FIT_NO_RETRY | (flags & SCAML_FIT_ZERO_UPPER);
-  scaml::FitParams f1{X, y, theta, p.n1, p.jit_cur, nullptr, L, alpha, p.q12, p.q12 + T, nullptr, p.info1, nullptr, Linv_diag, T, N1, D, fl};
+  scaml::FitParams f1{X, y, theta, p.n1, p.jit_cur, nullptr, L, alpha, p.q12, p.q12 + T, nullptr, p.info1, nullptr, Linv_diag, T, N1, D, fl | scaml::FIT_FORWARD_ONLY};
   const scaml::FitBlockParams b1{(long long)N * D, N, (long long)N * N, (long long)NBT * 256, p.active, N};
   scaml::FitParams f2{nullptr, p.r2 + N1, nullptr, p.n2, nullptr, p.S, L + (size_t)N1 * N + N1, alpha + N1, p.q12 + 2 * (size_t)T, p.q12 + 3 * (size_t)T,
                       nullptr, p.info2, nullptr, Linv_diag + (size_t)(N1 / 16) * 256, T, N2, 1, fl};
