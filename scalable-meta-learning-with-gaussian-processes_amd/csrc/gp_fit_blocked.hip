@@ -82,9 +82,9 @@ __device__ __forceinline__ double bk_sqdist(const double* a, const double* b, in
 // ---- L21^T = L11^-1 K12 by column strips, r2 = y2 - L21 v1 -------------------------------------------------------------
 // One wave owns one strip (16 points of block 2): its 16 blocks Z_0..Z_15 live in hand-managed AGPRs in the MFMA C/D
 // layout = the B-operand layout (csrc/gf_tiles.hpp), so a finished block feeds the next products from the registers it
-// was computed in.  The four waves of a workgroup advance in lockstep over the block rows of L11; row block kb (with
-// W_kb = L_kb,kb^-1 in place of the diagonal block) is staged once per workgroup in LDS by global_load_lds_dwordx4, one
-// step ahead.  Step kb:  ACC = K12 block (kernel function, VALU);  ACC -= L[kb][j] Z_j, j < kb;  Z_kb = W_kb ACC.
+// was computed in.  The four strips of a workgroup advance in lockstep over the block rows of L11; row block kb (with
+// W_kb = L_kb,kb^-1 in place of the diagonal block) is staged once per workgroup in LDS by global_load_lds_dwordx4, two
+// steps ahead.  Step kb:  ACC = K12 block (kernel function, VALU);  ACC -= L[kb][j] Z_j, j < kb;  Z_kb = W_kb ACC.
 template <int KB>
 __device__ __forceinline__ void bk_solve_step(const double* pa) {
   GfOps cur = gf_load_ops(pa, 4);
@@ -118,17 +118,21 @@ __device__ __forceinline__ void bk_stage_strip(double* tr, double* img, const do
 
 #define BK_STEP_CASE(K) case K: bk_solve_step<K>(pa); break;
 
-// SMALLD (D <= 8): the points are staged zero-padded to 8 dimensions, the lane's own block-2 point sits in registers and
-// the distance loops have a constant trip count.
+// Eight waves: waves 0-3 own the four strips (matrix core), waves 4-7 are their helpers on the same SIMDs -- helper w + 4
+// evaluates the kernel-function block of strip w for the NEXT step into LDS and issues the staging loads, i.e. the VALU and
+// memory work runs under the MFMA chain of the wave it shares a SIMD with.  One barrier per step.
+// SMALLD (D <= 8): the points are staged zero-padded to 8 dimensions, the helper lane's own block-2 point sits in registers
+// and the distance loops have a constant trip count.
 template <int KIND, bool SMALLD>
-__global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams p) {
-  constexpr int NP = BK_N1, PA = NP + 2, BUF = 16 * PA, NW = 4, TPB = 256;
+__global__ __launch_bounds__(512) void gp_blocked_solve_kernel(BlockedFitParams p) {
+  constexpr int NP = BK_N1, PA = NP + 2, BUF = 16 * PA, TPB = 512;
   extern __shared__ double lds[];
   const int N = p.N, D = p.D;
   const int DP = SMALLD ? 9 : (D | 1);   // odd pitch of the staged points
   const int DS = SMALLD ? 8 : D;         // staged dimensions
   double* buf = lds;                     // [3][BUF]: row blocks of L11, two steps ahead
-  double* X1s = buf + 3 * BUF;           // [NP][DP] block-1 points / lengthscale
+  double* kbuf = buf + 3 * BUF;          // [2][4][256] kernel-function blocks (register images), one step ahead
+  double* X1s = kbuf + 2 * 4 * 256;      // [NP][DP] block-1 points / lengthscale
   double* X2s = X1s + NP * DP;           // [64][DP] this workgroup's block-2 points / lengthscale
   double* a1s = X2s + 64 * DP;           // [NP] v1 = L11^-1 y1
   double* exptab = a1s + NP;             // [64]
@@ -139,6 +143,8 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   if (p.active[task] == 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool helper = wave >= 4;
+  const int sw = wave & 3;               // strip of this wave (owner) / of the wave this one helps
   const int lc = lane & 15, lq = lane >> 4;
   const int n1 = p.n1[task], n2 = p.n2[task];
   const int NBT = (N + 15) / 16;
@@ -150,15 +156,14 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
 
   typedef __attribute__((address_space(1))) void gvoid_t;
   typedef __attribute__((address_space(3))) void lvoid_t;
-  // row block kb of L11: 16 kb columns of L, then the 16 of W_kb (16-byte pieces; N % 16 == 0).  A wave moves four rows:
-  // 4 wave-instructions for kb <= 7, 8 beyond (the step loop counts them in its s_waitcnt).
+  // row block kb of L11: 16 kb columns of L, then the 16 of W_kb (16-byte pieces; N % 16 == 0).  A helper wave moves four
+  // rows: 4 wave-instructions for kb <= 7, 8 beyond (the step loop counts them in its s_waitcnt).
   auto dma_step = [&](int kb) {
     double* b = buf + (kb % 3) * BUF;
-    constexpr int RPW = 16 / NW;
     const int nch = 8 * kb + 8;
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int r = wave * RPW + rr;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = sw * 4 + rr;
       const double* lrow = Lg + (size_t)(16 * kb + r) * N;
       const double* wrow = Wg + (size_t)kb * 256 + r * 16 - 16 * kb;
       for (int c0 = 0; c0 < nch; c0 += 64) {
@@ -171,8 +176,10 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   };
 
   BK_STAMP_INIT(sg == 0 && tid == 0);
-  dma_step(0);
-  dma_step(1);
+  if (helper) {
+    dma_step(0);
+    dma_step(1);
+  }
   exp2_table_init(exptab, tid);
   if (tid < DS) invl[tid] = tid < D ? 1.0 / th[tid] : 0.0;
   __syncthreads();
@@ -185,23 +192,20 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
     X2s[q * DP + d] = (pt < n2 && d < D) ? Xg[(size_t)(BK_N1 + pt) * D + d] * invl[d] : 0.0;
   }
   for (int r = tid; r < NP; r += TPB) a1s[r] = r < n1 ? p.alpha[(size_t)task * N + r] : 0.0;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int c = 4 * sg + wave;              // this wave's strip
+  const int c = 4 * sg + sw;                // the strip
   const int colpt = 16 * c + lc;            // its point on this lane (index inside block 2)
   const bool col_ok = colpt < n2;
-  const double* xc = X2s + (16 * wave + lc) * DP;
+  const double* xc = X2s + (16 * sw + lc) * DP;
   double xcr[8];
   if constexpr (SMALLD) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) xcr[d] = xc[d];
   }
-  double macc = 0.0;                        // lane's share of (L21 v1) at its point
-  BK_STAMP(0);
-  for (int kb = 0; kb < BK_NB1; ++kb) {
-    if (kb + 2 < BK_NB1) dma_step(kb + 2);  // into the buffer step kb - 1 read from: everybody is past the barrier that ended it
-    double kv[4];
+  // kernel-function block (kb, strip) as the matrix core wants it: lane (lc, lq) register g = os k(x1[16 kb + lq + 4 g], x2[16 c + lc])
+  auto eval_block = [&](int kb) {
+    double* out = kbuf + ((kb & 1) * 4 + sw) * 256 + lane;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int row = 16 * kb + lq + 4 * g;
@@ -218,27 +222,41 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
         d2 = bk_sqdist(X1s + row * DP, xc, D);
       }
       const double k = os * kernel_from_sqdist<KIND>(d2, exptab);
-      kv[g] = (row < n1 && col_ok) ? k : 0.0;
+      out[64 * g] = (row < n1 && col_ok) ? k : 0.0;
     }
-    BK_STAMP(1 + 4 * kb);   // kernel values done
-    GF_DRAIN();   // (the previous step's closing product may still be reading ACC)
-    gf_acc_set(kv[0], kv[1], kv[2], kv[3]);
-    const double* pa = buf + (kb % 3) * BUF + lc * PA + lq;   // A operand: L[16 kb + lc][16 j + lq + 4 m]
-    switch (kb) {
-      BK_STEP_CASE(0) BK_STEP_CASE(1) BK_STEP_CASE(2) BK_STEP_CASE(3) BK_STEP_CASE(4) BK_STEP_CASE(5) BK_STEP_CASE(6) BK_STEP_CASE(7)
-      BK_STEP_CASE(8) BK_STEP_CASE(9) BK_STEP_CASE(10) BK_STEP_CASE(11) BK_STEP_CASE(12) BK_STEP_CASE(13) BK_STEP_CASE(14)
-      BK_STEP_CASE(15)
-      default: break;
+  };
+  if (helper) {
+    eval_block(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  BK_STAMP(0);
+  for (int kb = 0; kb < BK_NB1; ++kb) {
+    if (helper) {
+      if (kb + 2 < BK_NB1) dma_step(kb + 2);  // into the buffer step kb - 1 read from: everybody is past the barrier that ended it
+      if (kb + 1 < BK_NB1) eval_block(kb + 1);
+      // this wave's pieces of row block kb + 1 have landed; those of kb + 2 (4 or 8 instructions, issued above) may be in flight
+      if (kb + 2 >= BK_NB1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (kb + 2 >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      const double* kin = kbuf + ((kb & 1) * 4 + sw) * 256 + lane;
+      const double k0 = kin[0], k1 = kin[64], k2 = kin[128], k3 = kin[192];
+      GF_DRAIN();   // (the previous step's closing product may still be reading ACC)
+      gf_acc_set(k0, k1, k2, k3);
+      const double* pa = buf + (kb % 3) * BUF + lc * PA + lq;   // A operand: L[16 kb + lc][16 j + lq + 4 m]
+      switch (kb) {
+        BK_STEP_CASE(0) BK_STEP_CASE(1) BK_STEP_CASE(2) BK_STEP_CASE(3) BK_STEP_CASE(4) BK_STEP_CASE(5) BK_STEP_CASE(6) BK_STEP_CASE(7)
+        BK_STEP_CASE(8) BK_STEP_CASE(9) BK_STEP_CASE(10) BK_STEP_CASE(11) BK_STEP_CASE(12) BK_STEP_CASE(13) BK_STEP_CASE(14)
+        BK_STEP_CASE(15)
+        default: break;
+      }
+      BK_STAMP(2 + 4 * kb);   // chain issued
     }
-    BK_STAMP(2 + 4 * kb);   // chain issued
-    // this wave's pieces of row block kb + 1 have landed; those of kb + 2 (4 or 8 instructions, issued above) may be in flight
-    if (kb + 2 >= BK_NB1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (kb + 2 >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    BK_STAMP(3 + 4 * kb);   // staged rows landed
     __syncthreads();
     BK_STAMP(4 + 4 * kb);   // barrier passed
   }
+  if (helper) return;
   GF_DRAIN();
   // the strip goes to memory as rows of L21 (and, on request, zeros into the mirrored block of the upper triangle)
   const int N2 = N - BK_N1;
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(256) void gp_blocked_solve_kernel(BlockedFitParams 
   double* tr = buf + wave * (16 * BK_TP);   // (everybody is past the barrier that ended the last step: the staging area is free)
   const bool zero_upper = (p.flags & SCAML_FIT_ZERO_UPPER) != 0;
   const bool strip_in = 16 * c < N2;        // (N2 is a multiple of 16: a strip is inside the matrix or not at all)
+  double macc = 0.0;                        // lane's share of (L21 v1) at its point
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h == 0) bk_stage_strip<0, 8>(tr, img, a1s, macc, col_ok, lc, lq);

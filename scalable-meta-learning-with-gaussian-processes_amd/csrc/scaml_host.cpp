@@ -243,7 +243,7 @@ int scaml_fit_blocked_max_n(void) { return 512; }
 
 static size_t blocked_solve_lds_bytes(int D) {
   const size_t dp = D <= 8 ? 9 : (size_t)(D | 1);   // (D <= 8: staged zero-padded to 8 dimensions)
-  return (3 * 16 * 258 + 256 * dp + 64 * dp + 256 + 64 + (D <= 8 ? 8 : (size_t)D) + 1) * sizeof(double);
+  return (3 * 16 * 258 + 2 * 4 * 256 + 256 * dp + 64 * dp + 256 + 64 + (D <= 8 ? 8 : (size_t)D) + 1) * sizeof(double);
 }
 
 int scaml_fit_blocked_max_d(void) {
@@ -330,7 +330,7 @@ int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* the
     }
     int rc = fit_common(f1, kind, stream, &b1);
     if (rc != SCAML_OK) return rc;
-    if ((e = hipModuleLaunchKernel(m.blk_solve[kind][D <= 8 ? 1 : 0], (unsigned)(t8 * nt), 1, 1, 256, 1, 1, (unsigned)lds_solve, st, nullptr, config)) != hipSuccess) {
+    if ((e = hipModuleLaunchKernel(m.blk_solve[kind][D <= 8 ? 1 : 0], (unsigned)(t8 * nt), 1, 1, 512, 1, 1, (unsigned)lds_solve, st, nullptr, config)) != hipSuccess) {
       set_error("hipModuleLaunchKernel(gp_blocked_solve)", e); return SCAML_E_LAUNCH;
     }
     if ((e = hipModuleLaunchKernel(m.blk_syrk[kind], (unsigned)(t8 * (nt * (nt + 1) / 2)), 1, 1, 512, 1, 1, (unsigned)lds_syrk, st, nullptr, config)) != hipSuccess) {

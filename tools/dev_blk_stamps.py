@@ -28,12 +28,12 @@ torch.cuda.synchronize()
 N2 = N - 256
 off = T * N2 * N2 * 8 + T * 65536 * 8
 r2 = ws[off:off + T * N * 8].view(torch.float64).view(T, N).cpu().numpy()
-tick = 0.01  # us per s_memtime tick (100 MHz)
+tick = 1.0   # s_memtime counts shader-clock cycles here
 st = np.median(r2[:, :128], axis=0) * tick
-print(f"strip solve: prologue {st[0]:.2f} us, end of loop {st[4 + 4 * 15]:.2f}, strip stored {st[70]:.2f}")
+print(f"strip solve (cycles): prologue {st[0]:.0f}, end of loop {st[4 + 4 * 15]:.0f}, strip stored {st[70]:.0f}")
 prev = st[0]
 for kb in range(16):
-    a, b, c, e = st[1 + 4 * kb], st[2 + 4 * kb], st[3 + 4 * kb], st[4 + 4 * kb]
-    print(f"  kb {kb:2d}: kernel values {a - prev:5.2f}  chain {b - a:5.2f}  wait rows {c - b:5.2f}  barrier {e - c:5.2f}")
+    b, e = st[2 + 4 * kb], st[4 + 4 * kb]
+    print(f"  kb {kb:2d}: owner wave: block read + chain {b - prev:6.0f} cycles, barrier (helper wave: loads, kernel block) {e - b:6.0f}")
     prev = e
-print(f"finish: mat-vec done at {st[100]:.2f} us, chain done at {st[101]:.2f} us")
+print(f"finish (cycles): mat-vec done at {st[100]:.0f}, chain done at {st[101]:.0f}")
