@@ -19,6 +19,10 @@ stats fit bench.py --steps 100 --warmup 10 --no-cpu-baseline
 stats grad bench.py --steps 50 --warmup 10 --no-cpu-baseline --step fit+grad
 stats posterior tools/prof_workloads.py posterior 10
 stats c5 tools/prof_workloads.py c5 5
+stats blocked tools/dev_fit512_time.py 32,512,6
+python3 tools/dev_fit512_time.py > $OUT/blocked_fit_timings.txt 2>&1 || true
+cat $OUT/blocked_fit_timings.txt
+[ -x tools/dp_pipe_probe ] && tools/dp_pipe_probe > $OUT/probe_dp_pipe.txt 2>&1 || true
 pmc() {   # name, kernel substring, program args...
   local name=$1 needle=$2; shift; shift
   for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
