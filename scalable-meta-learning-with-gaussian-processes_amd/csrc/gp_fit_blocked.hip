@@ -417,26 +417,32 @@ __device__ __forceinline__ void bk_finish_load(double (&dst)[4], const double* L
 }
 
 template <int KB>
-__device__ __forceinline__ void bk_finish_step(const double (&lrow)[4], const double* Wl, double* w, double* u, int q, int j, int lane) {
-  __syncthreads();   // w_kb is complete (the previous step's atomics have landed)
+__device__ __forceinline__ void bk_finish_step(const double (&lrow)[4], const double* Wl, const double* w, double (*pw)[BK_N1], double* u, double& mine,
+                                               int q, int j, int lane) {
+  __syncthreads();   // the four quarters' running sums for block KB are in pw
   // u_kb[c] on lane (c = lane % 16, any lane / 16): every wave computes all of it
   const int c = lane & 15, rg = lane >> 4;
   double xv = 0.0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xv = __builtin_fma(Wl[KB * 256 + (4 * rg + i) * 16 + c], w[16 * KB + 4 * rg + i], xv);
+  for (int i = 0; i < 4; ++i) {
+    const int r = 16 * KB + 4 * rg + i;
+    const double wr = w[r] - ((pw[0][r] + pw[1][r]) + (pw[2][r] + pw[3][r]));   // fixed order: bit-reproducible
+    xv = __builtin_fma(Wl[KB * 256 + (4 * rg + i) * 16 + c], wr, xv);
+  }
   xv = sum_lane_groups(xv);
   if (q == 0 && j < 16) u[16 * KB + j] = xv;
   if constexpr (KB > 0) {
-    double s = 0.0;
+    // thread (q, j) keeps ITS share of sum_r L[r][j] u[r] over all steps in a register and hands it over when column j's block is next
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s = __builtin_fma(lrow[i], readlane_f64(xv, 4 * q + i), s);
-    if (j < 16 * KB) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)(w + j), -s);
+    for (int i = 0; i < 4; ++i) mine = __builtin_fma(lrow[i], readlane_f64(xv, 4 * q + i), mine);
+    if (j >= 16 * (KB - 1) && j < 16 * KB) pw[q][j] = mine;
   }
 }
 
 extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(BlockedFitParams p) {
   __shared__ double Wl[BK_NB1 * 256];
   __shared__ double part[4][BK_N1];
+  __shared__ double pw[4][BK_N1];
   __shared__ double a2s[BK_N1];
   __shared__ double w[BK_N1];
   __shared__ double u[BK_N1];
@@ -497,19 +503,21 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
   for (int i = 0; i < 4; ++i) Wl[tid + 1024 * i] = wl[i];
   __syncthreads();
   if (tid < BK_N1) w[tid] = (tid < n1 ? al[tid] : 0.0) - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));   // v1 - L21^T alpha2
+  pw[q][j] = 0.0;
+  double mine = 0.0;
   BK_STAMP(100);   // mat-vec done
-  bk_finish_step<15>(ring[7], Wl, w, u, q, j, lane); bk_finish_load<7>(ring[7], Lg, N, q, j);
-  bk_finish_step<14>(ring[6], Wl, w, u, q, j, lane); bk_finish_load<6>(ring[6], Lg, N, q, j);
-  bk_finish_step<13>(ring[5], Wl, w, u, q, j, lane); bk_finish_load<5>(ring[5], Lg, N, q, j);
-  bk_finish_step<12>(ring[4], Wl, w, u, q, j, lane); bk_finish_load<4>(ring[4], Lg, N, q, j);
-  bk_finish_step<11>(ring[3], Wl, w, u, q, j, lane); bk_finish_load<3>(ring[3], Lg, N, q, j);
-  bk_finish_step<10>(ring[2], Wl, w, u, q, j, lane); bk_finish_load<2>(ring[2], Lg, N, q, j);
-  bk_finish_step<9>(ring[1], Wl, w, u, q, j, lane); bk_finish_load<1>(ring[1], Lg, N, q, j);
-  bk_finish_step<8>(ring[0], Wl, w, u, q, j, lane);
-  bk_finish_step<7>(ring[7], Wl, w, u, q, j, lane); bk_finish_step<6>(ring[6], Wl, w, u, q, j, lane);
-  bk_finish_step<5>(ring[5], Wl, w, u, q, j, lane); bk_finish_step<4>(ring[4], Wl, w, u, q, j, lane);
-  bk_finish_step<3>(ring[3], Wl, w, u, q, j, lane); bk_finish_step<2>(ring[2], Wl, w, u, q, j, lane);
-  bk_finish_step<1>(ring[1], Wl, w, u, q, j, lane); bk_finish_step<0>(ring[0], Wl, w, u, q, j, lane);
+  bk_finish_step<15>(ring[7], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<7>(ring[7], Lg, N, q, j);
+  bk_finish_step<14>(ring[6], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<6>(ring[6], Lg, N, q, j);
+  bk_finish_step<13>(ring[5], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<5>(ring[5], Lg, N, q, j);
+  bk_finish_step<12>(ring[4], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<4>(ring[4], Lg, N, q, j);
+  bk_finish_step<11>(ring[3], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<3>(ring[3], Lg, N, q, j);
+  bk_finish_step<10>(ring[2], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<2>(ring[2], Lg, N, q, j);
+  bk_finish_step<9>(ring[1], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<1>(ring[1], Lg, N, q, j);
+  bk_finish_step<8>(ring[0], Wl, w, pw, u, mine, q, j, lane);
+  bk_finish_step<7>(ring[7], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<6>(ring[6], Wl, w, pw, u, mine, q, j, lane);
+  bk_finish_step<5>(ring[5], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<4>(ring[4], Wl, w, pw, u, mine, q, j, lane);
+  bk_finish_step<3>(ring[3], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<2>(ring[2], Wl, w, pw, u, mine, q, j, lane);
+  bk_finish_step<1>(ring[1], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<0>(ring[0], Wl, w, pw, u, mine, q, j, lane);
   __syncthreads();
   BK_STAMP(101);   // chain done
   if (tid < n1) al[tid] = u[tid];
