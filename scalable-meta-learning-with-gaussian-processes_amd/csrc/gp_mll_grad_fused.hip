@@ -84,20 +84,27 @@ __device__ __forceinline__ void gf_bwd_step(int cA, int cB, int last, const doub
   }
 }
 
-// kernel value k (without outputscale) and h with dk/dl_d = h * delta_d^2 / l_d^3
+// kernel value k (without outputscale) and h with dk/dl_d = GF_HSCALE<KIND> * h * delta_d^2 / l_d^3 (the caller folds the constant
+// into the outputscale).  Matern: the fused fit's instruction sequence (scaml_common.hpp: kernel_from_sqdist_scaled) -- sqrt straight
+// from the f32 seed, d2 clamped to [1e-30, 1e5] so that exp needs no clamp of its own.
+template <int KIND>
+__device__ __forceinline__ constexpr double gf_hscale() { return KIND == 0 ? 1.0 : 5.0 / 3.0; }
 template <int KIND>
 __device__ __forceinline__ void gf_kernel_and_dfactor(double d2, const double* exptab, double& k, double& h) {
   if (KIND == 0) {
-    k = exp_neg(-0.5 * d2, exptab);
+    k = exp_neg_t<true>(-0.5 * d2, exptab);
     h = k;
   } else {
-    double dd = d2 < 1e-30 ? 1e-30 : d2;
-    dd = dd > 1e30 ? 1e30 : dd;
-    const double r = sqrt_from_rinv(dd, rsqrt_seeded(dd));
+    const double dd = vmin_f64(vmax_f64(d2, 1e-30), 1e5);   // (bare v_max / v_min: one instruction each)
+    const double y = (double)__builtin_amdgcn_rsqf((float)dd);
+    const double g = dd * y;
+    const double e = __builtin_fma(-g, y, 1.0);
+    const double r = __builtin_fma(g * e, __builtin_fma(e, 0.375, 0.5), g);
     const double s5 = 2.2360679774997896964;
-    const double e = exp_neg(-s5 * r, exptab);
-    k = __builtin_fma(__builtin_fma(r, 5.0 / 3.0, s5), r, 1.0) * e;
-    h = (5.0 / 3.0) * __builtin_fma(s5, r, 1.0) * e;
+    const double ex = exp_neg_t<false>(-s5 * r, exptab);
+    const double p1 = __builtin_fma(s5, r, 1.0);
+    k = __builtin_fma(r * (5.0 / 3.0), r, p1) * ex;
+    h = p1 * ex;
   }
 }
 
@@ -123,8 +130,8 @@ struct GfStrip {
 // squared distances of the block from one MFMA chain as well (expanded form, norms as a third k-step): the VALU is left
 // with the kernel function and G.  At the strip's last block (kb == c) the sums over a are complete and folded into the
 // lane's two lengthscale partials (dimensions lq and lq + 4).
-template <int KIND>
-__device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int kb, int c, int n, const double* Xs, const double* als,
+template <int KIND, bool SETTLE_T>
+__device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int kb, int c, int n, const double* Xs, const double* Xq, const double* als,
                                             const double* exptab, double os, double& g_os, double& g_noise, double& pd0,
                                             double& pd1, int lc, int lq) {
   const int col = 16 * c + lc;
@@ -137,32 +144,48 @@ __device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int k
   d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(-2.0 * xap[lq + 4], xc1, d2v, 0, 0, 0);
   d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(lq == 0 ? na : (lq == 1 ? 1.0 : 0.0), lq == 0 ? 1.0 : (lq == 1 ? nc : 0.0), d2v, 0, 0, 0);
   d2v = gf_settle(d2v);
-  const double wgt = kb == c ? 1.0 : 2.0;   // off-diagonal blocks stand for both triangles
   const double ac = als[col];
+  const double hs = os * gf_hscale<KIND>();
   d4_t GH;
+  if (kb != c && 16 * kb + 16 <= n) {
+    // wave-uniform fast path (120 of the 136 blocks at N = 256): an off-diagonal block entirely inside the n valid points has no
+    // diagonal element and needs no masks -- ~10 VALU instructions per element less
+    const double ac2 = 2.0 * ac;             // off-diagonal blocks stand for both triangles
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int row = 16 * kb + lq + 4 * g;
-    double d2 = d2v[g] > 0.0 ? d2v[g] : 0.0;
-    if (row == col) d2 = 0.0;
-    double k, h;
-    gf_kernel_and_dfactor<KIND>(d2, exptab, k, h);
-    const bool ok = row < n && col < n;
-    const double Gv = ok ? wgt * (als[row] * ac - zt[64 * g]) : 0.0;
-    GH[g] = Gv * os * h;
-    g_os = __builtin_fma(Gv, k, g_os);
-    if (row == col) g_noise += Gv;
-    st.cs += GH[g];
+    for (int g = 0; g < 4; ++g) {
+      double k, h;
+      gf_kernel_and_dfactor<KIND>(vmax_f64(d2v[g], 0.0), exptab, k, h);
+      const double Gv = __builtin_fma(als[16 * kb + lq + 4 * g], ac2, -2.0 * zt[64 * g]);
+      GH[g] = (Gv * hs) * h;
+      g_os = __builtin_fma(Gv, k, g_os);
+      st.cs += GH[g];
+    }
+  } else {
+    const double wgt = kb == c ? 1.0 : 2.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + lq + 4 * g;
+      double d2 = d2v[g] > 0.0 ? d2v[g] : 0.0;
+      if (row == col) d2 = 0.0;
+      double k, h;
+      gf_kernel_and_dfactor<KIND>(d2, exptab, k, h);
+      const bool ok = row < n && col < n;
+      const double Gv = ok ? wgt * (als[row] * ac - zt[64 * g]) : 0.0;
+      GH[g] = (Gv * hs) * h;
+      g_os = __builtin_fma(Gv, k, g_os);
+      if (row == col) g_noise += Gv;
+      st.cs += GH[g];
+    }
   }
   // T += [X_a^T; (X_a^2)^T] GH: A[i = lc][k = lq + 4 m] = x_{a, k}[d = lc & 7], squared for the rows i >= 8
-  const double* xk = Xs + (16 * kb + lq) * GF_DP + (lc & 7);
-  const bool sq = lc >= 8;
+  // (the squares are staged next to the coordinates: a pointer select per block instead of a multiply and a select per operand)
+  const double* xk = (lc >= 8 ? Xq : Xs) + (16 * kb + lq) * GF_DP + (lc & 7);
   d4_t T = st.T;
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const double v = xk[4 * m * GF_DP];
-    T = __builtin_amdgcn_mfma_f64_16x16x4f64(sq ? v * v : v, GH[m], T, 0, 0, 0);
-  }
+  for (int m = 0; m < 4; ++m) T = __builtin_amdgcn_mfma_f64_16x16x4f64(xk[4 * m * GF_DP], GH[m], T, 0, 0, 0);
+  // (register-staged variants spill: hipcc once placed a scratch reload into the accumulator 16 wait states behind the last MFMA --
+  //  the build's hazard audit refused the code object; those variants pay 19 idle cycles per block for a guaranteed distance)
+  if constexpr (SETTLE_T) T = gf_settle(T);
   st.T = T;
   if (kb == c) {
     const d4_t Tf = gf_settle(T);
@@ -188,7 +211,8 @@ __global__ __launch_bounds__(NBT * 32 / SPLIT) void gp_mll_grad_fused_kernel(Mll
   extern __shared__ double lds[];
   double* buf = lds;                     // [2][BUF]
   double* Xs = buf + 2 * BUF;            // [NP][GF_DP] points scaled by 1 / lengthscale, zero-padded to 8 dimensions; [8] = |x|^2
-  double* als = Xs + NP * GF_DP;         // [NP] alpha (0 past n)
+  double* Xq = Xs + NP * GF_DP;          // [NP][GF_DP] their squares, coordinate by coordinate
+  double* als = Xq + NP * GF_DP;         // [NP] alpha (0 past n)
   double* zs_all = als + NP;             // [NW][2][256] finished K^-1 blocks (register images)
   double* exptab = zs_all + NW * 512;    // [64]
   double* invl = exptab + 64;            // [8]
@@ -335,6 +359,7 @@ __global__ __launch_bounds__(NBT * 32 / SPLIT) void gp_mll_grad_fused_kernel(Mll
     for (int d = 0; d < GF_DMAX; ++d) {
       const double v = (r < n && d < D) ? p.X[((size_t)task * N + r) * D + d] * invl[d] : 0.0;
       Xs[r * GF_DP + d] = v;
+      Xq[r * GF_DP + d] = v * v;
       nrm = __builtin_fma(v, v, nrm);
     }
     Xs[r * GF_DP + 8] = nrm;
@@ -362,8 +387,8 @@ __global__ __launch_bounds__(NBT * 32 / SPLIT) void gp_mll_grad_fused_kernel(Mll
 #endif
   auto epilogue = [&](int kb) {
 #ifndef GF_NO_EPI
-    if (kb >= cA) gf_epilogue<KIND>(stA, zs + lane, kb, cA, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
-    if (kb >= cB) gf_epilogue<KIND>(stB, zs + 256 + lane, kb, cB, n, Xs, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
+    if (kb >= cA) gf_epilogue<KIND, !DMA>(stA, zs + lane, kb, cA, n, Xs, Xq, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
+    if (kb >= cB) gf_epilogue<KIND, !DMA>(stB, zs + 256 + lane, kb, cB, n, Xs, Xq, als, exptab, os, g_os, g_noise, pd0, pd1, lc, lq);
 #endif
   };
   for (int t = 0; t < 2 * NB; ++t) {
