@@ -150,16 +150,20 @@ __device__ __forceinline__ void gf_epilogue(GfStrip& st, const double* zt, int k
   if (kb != c && 16 * kb + 16 <= n) {
     // wave-uniform fast path (120 of the 136 blocks at N = 256): an off-diagonal block entirely inside the n valid points has no
     // diagonal element and needs no masks -- ~10 VALU instructions per element less
-    const double ac2 = 2.0 * ac;             // off-diagonal blocks stand for both triangles
+    // (off-diagonal blocks stand for both triangles: the factor 2 rides on the outputscale factor and on a separate sum)
+    const double hs2 = 2.0 * hs;
+    double gk = 0.0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       double k, h;
-      gf_kernel_and_dfactor<KIND>(vmax_f64(d2v[g], 0.0), exptab, k, h);
-      const double Gv = __builtin_fma(als[16 * kb + lq + 4 * g], ac2, -2.0 * zt[64 * g]);
-      GH[g] = (Gv * hs) * h;
-      g_os = __builtin_fma(Gv, k, g_os);
+      // (Matern clamps d2 at 1e-30 itself; RBF must not see the slightly negative values of the expanded form)
+      gf_kernel_and_dfactor<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], exptab, k, h);
+      const double Gh = __builtin_fma(als[16 * kb + lq + 4 * g], ac, -zt[64 * g]);   // half of G
+      GH[g] = (Gh * hs2) * h;
+      gk = __builtin_fma(Gh, k, gk);
       st.cs += GH[g];
     }
+    g_os = __builtin_fma(2.0, gk, g_os);
   } else {
     const double wgt = kb == c ? 1.0 : 2.0;
 #pragma unroll
