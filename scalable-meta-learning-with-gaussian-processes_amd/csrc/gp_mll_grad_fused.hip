@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NBT * 32 / SPLIT) void gp_mll_grad_fused_kernel(Mll
   extern __shared__ double lds[];
   double* buf = lds;                     // [2][BUF]
   double* Xs = buf + 2 * BUF;            // [NP][GF_DP] points scaled by 1 / lengthscale, zero-padded to 8 dimensions; [8] = |x|^2
-  double* Xq = Xs + NP * GF_DP;          // [NP][GF_DP] their squares, coordinate by coordinate
+  double* Xq = Xs + NP * GF_DP + 16;     // [NP][GF_DP] their squares, coordinate by coordinate (16 banks away: lanes lc and lc + 8 read the two arrays together)
   double* als = Xq + NP * GF_DP;         // [NP] alpha (0 past n)
   double* zs_all = als + NP;             // [NW][2][256] finished K^-1 blocks (register images)
   double* exptab = zs_all + NW * 512;    // [64]

@@ -600,7 +600,7 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
   if (N <= 256 && D <= 8 && !g_force_two_launch_grad) {
     const int sc = N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3));
     const int nbt = 2 << sc, np = 16 * nbt, nw = nbt / 2;
-    const size_t lds = ((size_t)2 * 16 * (np + 2) + (size_t)2 * np * 9 + np + (size_t)nw * 512 + 64 + 8 + (size_t)nw * 10) * sizeof(double);
+    const size_t lds = ((size_t)2 * 16 * (np + 2) + (size_t)2 * np * 9 + 16 + np + (size_t)nw * 512 + 64 + 8 + (size_t)nw * 10) * sizeof(double);
     scaml::MllGradFusedParams p{X, theta, L, Linv_diag, alpha, n_points, partials, T, N, D};
     size_t psize = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
