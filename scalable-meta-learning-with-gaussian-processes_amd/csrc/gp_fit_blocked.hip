@@ -193,36 +193,60 @@ __global__ __launch_bounds__(512) void gp_blocked_solve_kernel(BlockedFitParams 
   }
   for (int r = tid; r < NP; r += TPB) a1s[r] = r < n1 ? p.alpha[(size_t)task * N + r] : 0.0;
   __syncthreads();
+  if constexpr (SMALLD) {   // |x|^2 into the ninth slot: the squared distances of a block come off the matrix core (expanded form)
+    for (int r = tid; r < NP + 64; r += TPB) {
+      double* xr = r < NP ? X1s + r * 9 : X2s + (r - NP) * 9;
+      double nrm = 0.0;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) nrm = __builtin_fma(xr[d], xr[d], nrm);
+      xr[8] = nrm;
+    }
+    __syncthreads();
+  }
 
   const int c = 4 * sg + sw;                // the strip
   const int colpt = 16 * c + lc;            // its point on this lane (index inside block 2)
   const bool col_ok = colpt < n2;
   const double* xc = X2s + (16 * sw + lc) * DP;
-  double xcr[8];
+  // SMALLD: B operands of the distance product, fixed for the kernel: X2[d = lq + 4 m][point lc], and the norm row
+  double xb0 = 0.0, xb1 = 0.0, xb2 = 0.0;
   if constexpr (SMALLD) {
-#pragma unroll
-    for (int d = 0; d < 8; ++d) xcr[d] = xc[d];
+    xb0 = xc[lq];
+    xb1 = xc[lq + 4];
+    xb2 = lq == 0 ? 1.0 : (lq == 1 ? xc[8] : 0.0);
   }
+  const bool strip_full = 16 * c + 16 <= n2;
+  // scaled Matern / RBF coefficients (the outputscale rides on the polynomial)
+  const double kc0 = os, kc1 = 2.2360679774997896964 * os, kc2 = (5.0 / 3.0) * os;
   // kernel-function block (kb, strip) as the matrix core wants it: lane (lc, lq) register g = os k(x1[16 kb + lq + 4 g], x2[16 c + lc])
   auto eval_block = [&](int kb) {
     double* out = kbuf + ((kb & 1) * 4 + sw) * 256 + lane;
+    if constexpr (SMALLD) {
+      // d2 = |a|^2 + |c|^2 - 2 a.c for the whole block from three MFMAs (A: -2 X1[point lc][d = lq + 4 m]; third k-step: the norms)
+      const double* xa = X1s + (16 * kb + lc) * 9;
+      d4_t d2v = {0.0, 0.0, 0.0, 0.0};
+      d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(-2.0 * xa[lq], xb0, d2v, 0, 0, 0);
+      d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(-2.0 * xa[lq + 4], xb1, d2v, 0, 0, 0);
+      d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(lq == 0 ? xa[8] : (lq == 1 ? 1.0 : 0.0), xb2, d2v, 0, 0, 0);
+      d2v = gf_settle(d2v);
+      if (strip_full && 16 * kb + 16 <= n1) {   // wave-uniform: nothing to mask
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = 16 * kb + lq + 4 * g;
-      double d2;
-      if constexpr (SMALLD) {
-        const double* xr = X1s + row * 9;
-        d2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const double uu = xr[d] - xcr[d];
-          d2 = __builtin_fma(uu, uu, d2);
-        }
+        for (int g = 0; g < 4; ++g) out[64 * g] = kernel_from_sqdist_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, kc1, kc2, exptab);
       } else {
-        d2 = bk_sqdist(X1s + row * DP, xc, D);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lq + 4 * g;
+          const double k = kernel_from_sqdist_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, kc1, kc2, exptab);
+          out[64 * g] = (row < n1 && col_ok) ? k : 0.0;
+        }
       }
-      const double k = os * kernel_from_sqdist<KIND>(d2, exptab);
-      out[64 * g] = (row < n1 && col_ok) ? k : 0.0;
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * kb + lq + 4 * g;
+        const double k = os * kernel_from_sqdist<KIND>(bk_sqdist(X1s + row * DP, xc, D), exptab);
+        out[64 * g] = (row < n1 && col_ok) ? k : 0.0;
+      }
     }
   };
   if (helper) {
