@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
 // latencies -- the substitution kernel above holds a 32 KB strip per WAVE and runs one wave per SIMD.
 // XCD-aware block map (see gp_mll_grad_kernel): the strips of one task share an L2.
 template <int KIND, bool COV>
-__global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams p) {
+__global__ __launch_bounds__(COV ? 256 : 512) void gp_posterior_linv_kernel(PosteriorParams p) {
+  // eight waves share one K_*^T strip in the plain pass (the row blocks are dealt 8 ways: twice the waves per byte of LDS to hide the
+  // L^-1 segment loads); the variant with the fused covariance block needs ~170 registers and stays at four
+  constexpr int NW = COV ? 4 : 8;
   extern __shared__ double lds[];
   const int N = p.N, D = p.D, M = p.M;
   const int NB = (N + 15) / 16, NP = NB * 16;
@@ -149,14 +152,18 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   const int lc = lane & 15, lq = lane >> 4;
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
-  // LDS: exp table [64] | alpha [NP] | invl [D] (+pad) | xq [D][16] | red [32] | K_*^T strip [NP][16] | xsT [D][NP] (optional)
+  // LDS: exp table [64] | alpha [NP] | invl [D4] | xq [D4][16] | red [32] | |xq|^2 [16] | |x|^2 [NP] | K_*^T strip [NP][16];
+  // D4 = D rounded up to the MFMA k-step, the extra entries are zeros.  (Round 2: the task's points are no longer staged -- they
+  // are MFMA operands read once per block straight from memory --, which keeps four workgroups on a CU instead of two.)
+  const int D4 = (D + 3) & ~3;
   double* exptab = lds;
   double* alpha_s = exptab + 64;
   double* invl = alpha_s + NP;
-  double* xqs = invl + D + (D & 1);
-  double* red = xqs + 16 * D;
-  double* Ks = red + 32;
-  double* xsT = Ks + NP * 16;
+  double* xqs = invl + D4;
+  double* red = xqs + 16 * D4;
+  double* nq = red + 32;
+  double* nr = nq + 16;
+  double* Ks = nr + NP;
 
   const double* Xg = p.X + (size_t)task * N * D;
   const double* th = p.theta + (size_t)task * (D + 2);
@@ -167,45 +174,71 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
   const int qc = 16 * strip + lc;   // this lane's query point
 
   exp2_table_init(exptab, tid);
-  for (int d = tid; d < D; d += blockDim.x) invl[d] = 1.0 / th[d];   // strided: D may exceed the 64 .. 256 threads
+  for (int d = tid; d < D4; d += blockDim.x) invl[d] = d < D ? 1.0 / th[d] : 0.0;   // strided: D may exceed the 256 threads
   if (tid < 32) red[tid] = 0.0;
   for (int r = tid; r < NP; r += blockDim.x) alpha_s[r] = r < n ? p.alpha[(size_t)task * N + r] : 0.0;
   __syncthreads();
-  if (p.x_in_lds) {
-    for (int r = tid; r < NP; r += blockDim.x) {
-      const bool in = r < n;
-      for (int d = 0; d < D; ++d) xsT[d * NP + r] = in ? Xg[(size_t)r * D + d] * invl[d] : 0.0;
+  for (int r = tid; r < NP; r += blockDim.x) {
+    double nrm = 0.0;
+    if (r < n) {
+      for (int d = 0; d < D; ++d) {
+        const double v = Xg[(size_t)r * D + d] * invl[d];
+        nrm = __builtin_fma(v, v, nrm);
+      }
     }
+    nr[r] = nrm;
   }
   if (tid < 16) {
     const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
-    for (int d = 0; d < D; ++d) xqs[d * 16 + lc] = qc < M ? Xqg[(size_t)qc * D + d] * invl[d] : 0.0;
+    double nrm = 0.0;
+    for (int d = 0; d < D4; ++d) {
+      const double v = (qc < M && d < D) ? Xqg[(size_t)qc * D + d] * invl[d] : 0.0;
+      xqs[d * 16 + lc] = v;
+      nrm = __builtin_fma(v, v, nrm);
+    }
+    nq[lc] = nrm;
   }
   __syncthreads();
 
   // ---- phase 1: cross-kernel strip into LDS (rows permuted inside each 16-block, see strip_row) + the mean
+  // Round 2: the squared distances of a 16 x 16 block come off the matrix core (expanded form |a|^2 + |c|^2 - 2 a.c: D4/4 k-steps
+  // over the coordinates + one over the norms) -- on gfx950 a VALU instruction costs what 1/8 of an fp64 MFMA costs, and nothing
+  // overlaps with it (profiles/r02_probe_dp_pipe.txt): 2 D VALU instructions per element became (D4/4 + 1) MFMAs per 256 elements;
+  // the kernel function itself in the fused fit's instruction sequence, masks only where a block straddles n.
   double mean_part = 0.0;
-  for (int kb = wave; kb < NB; kb += 4) {
-    double d2[4] = {0.0, 0.0, 0.0, 0.0};
-    const int row0 = 16 * kb + lq;
-#pragma unroll 2
-    for (int d = 0; d < D; ++d) {
-      const double xc = xqs[d * 16 + lc];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = row0 + 4 * g;
-        const double xr = p.x_in_lds ? xsT[d * NP + row] : (row < n ? Xg[(size_t)row * D + d] * invl[d] : 0.0);
-        const double df = xr - xc;
-        d2[g] = __builtin_fma(df, df, d2[g]);
+  {
+    const double kc0 = os, kc1 = 2.2360679774997896964 * os, kc2 = (5.0 / 3.0) * os;
+    const double bn = lq == 0 ? 1.0 : (lq == 1 ? nq[lc] : 0.0);
+    for (int kb = wave; kb < NB; kb += NW) {
+      d4_t d2v = {0.0, 0.0, 0.0, 0.0};
+      const int arow = 16 * kb + lc;
+      const double* xa = Xg + (size_t)(arow < n ? arow : 0) * D;
+      const double* xb = xqs + lq * 16 + lc;
+      for (int s4 = 0; s4 < D4; s4 += 4) {
+        const int d = s4 + lq;
+        const double av = (arow < n && d < D) ? -2.0 * invl[d] * xa[d] : 0.0;   // A[i = lc][k = lq]: point 16 kb + lc, coordinate d
+        d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(av, xb[s4 * 16], d2v, 0, 0, 0);
       }
-    }
+      d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(lq == 0 ? nr[arow] : (lq == 1 ? 1.0 : 0.0), bn, d2v, 0, 0, 0);
+      asm volatile("s_nop 15\n\ts_nop 2" : "+v"(d2v));   // (gfx950: the last result pair is not interlocked for VALU reads)
+      const int row0 = 16 * kb + lq;
+      if (16 * kb + 16 <= n) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = row0 + 4 * g;
-      double kv = os * kernel_from_sqdist<KIND>(d2[g], exptab);
-      kv = row < n ? kv : 0.0;
-      Ks[(16 * kb + strip_row(lq, g)) * 16 + lc] = kv;
-      mean_part = __builtin_fma(kv, alpha_s[row], mean_part);
+        for (int g = 0; g < 4; ++g) {
+          const double kv = kernel_from_sqdist_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, kc1, kc2, exptab);
+          Ks[(16 * kb + strip_row(lq, g)) * 16 + lc] = kv;
+          mean_part = __builtin_fma(kv, alpha_s[row0 + 4 * g], mean_part);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + 4 * g;
+          double kv = kernel_from_sqdist_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, kc1, kc2, exptab);
+          kv = row < n ? kv : 0.0;
+          Ks[(16 * kb + strip_row(lq, g)) * 16 + lc] = kv;
+          mean_part = __builtin_fma(kv, alpha_s[row], mean_part);
+        }
+      }
     }
   }
   mean_part = sum_lane_groups(mean_part);
@@ -224,9 +257,9 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
     const bool n_even = (N & 1) == 0;
     const double* VAg = p.VA ? p.VA + (size_t)task * N * p.Ma : nullptr;
     for (int it = 0;; ++it) {
-      const int kb = (it & 1) ? (it + 1) * 4 - 1 - wave : it * 4 + wave;
+      const int kb = (it & 1) ? (it + 1) * NW - 1 - wave : it * NW + wave;
       if (kb >= NB) {
-        if (it * 4 >= NB) break;
+        if (it * NW >= NB) break;
         continue;
       }
       const int arow = 16 * kb + lc;
@@ -245,7 +278,7 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
         }
       }
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      acc = block_row_accumulate<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
+      acc = block_row_accumulate_deep<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         var_part = __builtin_fma(acc[g], acc[g], var_part);
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(256) void gp_posterior_linv_kernel(PosteriorParams 
     // the four waves' partial tiles are added in a fixed order in the (now free) K_*^T strip, then
     // cov[a][c] = s^2 (os k(xq_a, xq_c) - (VA^T V)[a][c]) for the Ma leading query points a and this strip's 16 points c
     double* cb = Ks;   // [nas][256] register images; nas * 256 <= NP * 16 is checked by the host (Ma <= N)
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       if (wave == w) {
 #pragma unroll
         for (int as = 0; as < MAXAS; ++as) {

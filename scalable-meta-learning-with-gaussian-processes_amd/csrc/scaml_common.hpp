@@ -217,6 +217,36 @@ __device__ __forceinline__ d4_t block_row_accumulate(d4_t acc, const double* Lro
   return acc;
 }
 
+// The same sum with the row segments FOUR blocks ahead: with one block of look-ahead a product (4 MFMAs, 256 cycles) cannot hide an
+// L2 round trip (~1,000 cycles) -- the L^-1 posterior pass spent three quarters of its time waiting for segments.
+template <bool NEG>
+__device__ __forceinline__ d4_t block_row_accumulate_deep(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
+                                                          const double* Vs, int j0, int kb, int lc, int lq) {
+  if (j0 >= kb) return acc;
+  auto ld = [&](int j) {
+    LRowSeg t = {{0.0, 0.0, 0.0, 0.0}};
+    if (j < kb) t = load_lrow_seg(Lrow, 16 * j + 4 * lq, rows_in && n_even && 16 * j + 16 <= n, row_ok, n);
+    return t;
+  };
+  auto use = [&](const LRowSeg& c, int j) {
+    const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a[m], vb[4 * m * 16], acc, 0, 0, NEG ? 1 : 0);
+  };
+  LRowSeg q0 = ld(j0), q1 = ld(j0 + 1), q2 = ld(j0 + 2), q3 = ld(j0 + 3);
+  for (int j = j0; j < kb; j += 4) {
+    use(q0, j);
+    q0 = ld(j + 4);
+    if (j + 1 < kb) use(q1, j + 1);
+    q1 = ld(j + 5);
+    if (j + 2 < kb) use(q2, j + 2);
+    q2 = ld(j + 6);
+    if (j + 3 < kb) use(q3, j + 3);
+    q3 = ld(j + 7);
+  }
+  return acc;
+}
+
 __device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
                                                  const double* Vs, int j0, int kb, int lc, int lq) {
   return block_row_accumulate<true>(acc, Lrow, row_ok, rows_in, n, n_even, Vs, j0, kb, lc, lq);

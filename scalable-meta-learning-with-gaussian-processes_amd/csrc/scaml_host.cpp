@@ -543,9 +543,10 @@ static int posterior_linv_common(const double* Xq, const double* X, const double
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   const int np = ((N + 15) / 16) * 16;
-  const size_t base = (size_t)(64 + np + D + (D & 1) + 16 * D + 32 + (size_t)np * 16) * sizeof(double);
-  const size_t with_x = base + (size_t)D * np * sizeof(double);
-  const bool xl = with_x <= 80 * 1024;   // keep at least two workgroups per CU
+  const int d4 = (D + 3) & ~3;   // query points, 1 / lengthscale zero-padded to the MFMA k-step
+  const size_t base = (size_t)(64 + np + d4 + 16 * d4 + 32 + 16 + np + (size_t)np * 16) * sizeof(double);
+  const bool xl = false;         // (the task's points are MFMA operands read from memory: nothing to stage)
+  const size_t with_x = base;
   if (base > 160 * 1024) return SCAML_E_TOOLARGE;
   scaml::PosteriorParams p{Xq, X, theta, Linv, nullptr, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0,
                            (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0, VA, cov, VA ? Ma : 0};
@@ -553,7 +554,7 @@ static int posterior_linv_common(const double* Xq, const double* X, const double
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const unsigned strips = (unsigned)((M + 15) / 16);
   const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * strips;   // XCD-aware (task, strip) map inside the kernel
-  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, 256, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
+  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, VA ? 256 : 512, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
                             nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
