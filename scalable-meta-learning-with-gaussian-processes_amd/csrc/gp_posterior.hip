@@ -400,11 +400,21 @@ extern "C" __global__ void scaml_weighted_task_sum_kernel(const double* __restri
                                          double* __restrict__ out) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= len) return;
+  // eight tasks' values in flight per thread (one load at a time left the pass latency-bound: 17 us for the 23 MB of the
+  // configs[4] covariance block); the sum itself stays in task order
   double s = 0.0;
-  for (int t = 0; t < T; ++t) {
-    if (active && !active[t]) continue;
-    const double c = power == 2 ? w[t] * w[t] : w[t];
-    s = __builtin_fma(c, in[(size_t)t * len + e], s);
+  for (int t0 = 0; t0 < T; t0 += 8) {
+    double v[8], c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int t = t0 + k;
+      const bool ok = t < T && (!active || active[t]);   // (a masked task is skipped, not multiplied by zero: its values may be NaN)
+      v[k] = ok ? in[(size_t)t * len + e] : 0.0;
+      const double wt = ok ? w[t] : 0.0;
+      c[k] = power == 2 ? wt * wt : wt;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = __builtin_fma(c[k], v[k], s);
   }
   out[e] = s;
 }
