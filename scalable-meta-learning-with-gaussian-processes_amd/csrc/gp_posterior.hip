@@ -136,10 +136,9 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
 // latencies -- the substitution kernel above holds a 32 KB strip per WAVE and runs one wave per SIMD.
 // XCD-aware block map (see gp_mll_grad_kernel): the strips of one task share an L2.
 template <int KIND, bool COV>
-__global__ __launch_bounds__(COV ? 256 : 512) void gp_posterior_linv_kernel(PosteriorParams p) {
-  // eight waves share one K_*^T strip in the plain pass (the row blocks are dealt 8 ways: twice the waves per byte of LDS to hide the
-  // L^-1 segment loads); the variant with the fused covariance block needs ~170 registers and stays at four
-  constexpr int NW = COV ? 4 : 8;
+__global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams p) {
+  // eight waves share one K_*^T strip (the row blocks are dealt 8 ways: twice the waves per byte of LDS to hide the L^-1 segment loads)
+  constexpr int NW = 8;
   extern __shared__ double lds[];
   const int N = p.N, D = p.D, M = p.M;
   const int NB = (N + 15) / 16, NP = NB * 16;
@@ -264,19 +263,6 @@ __global__ __launch_bounds__(COV ? 256 : 512) void gp_posterior_linv_kernel(Post
       }
       const int arow = 16 * kb + lc;
       const double* Lrow = Li + (size_t)(arow < N ? arow : 0) * N;
-      // (fused covariance block: the VA operands of this row block are requested first and land under the products below)
-      double va[MAXAS][4];
-      if (nas) {
-#pragma unroll
-        for (int as = 0; as < MAXAS; ++as) {
-          const int ac = 16 * as + lc;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int row = 16 * kb + lq + 4 * m;
-            va[as][m] = (as < nas && row < n && ac < p.Ma) ? VAg[(size_t)row * p.Ma + ac] : 0.0;
-          }
-        }
-      }
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
       acc = block_row_accumulate_deep<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
 #pragma unroll
@@ -292,11 +278,20 @@ __global__ __launch_bounds__(COV ? 256 : 512) void gp_posterior_linv_kernel(Post
         d4_t vb = acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) vb[g] = (16 * kb + lq + 4 * g) < n ? vb[g] : 0.0;
+        // (the VA operands are fetched strip by strip: holding all six strips' worth across the products above cost 48 registers
+        //  and with them half of the waves a CU can keep in flight)
 #pragma unroll
         for (int as = 0; as < MAXAS; ++as) {
           if (as < nas) {
+            const int ac = 16 * as + lc;
+            double va[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) cacc[as] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[as][m], vb[m], cacc[as], 0, 0, 0);
+            for (int m = 0; m < 4; ++m) {
+              const int row = 16 * kb + lq + 4 * m;
+              va[m] = (row < n && ac < p.Ma) ? VAg[(size_t)row * p.Ma + ac] : 0.0;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) cacc[as] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[m], vb[m], cacc[as], 0, 0, 0);
           }
         }
       }

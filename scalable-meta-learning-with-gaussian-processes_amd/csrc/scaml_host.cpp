@@ -554,7 +554,7 @@ static int posterior_linv_common(const double* Xq, const double* X, const double
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const unsigned strips = (unsigned)((M + 15) / 16);
   const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * strips;   // XCD-aware (task, strip) map inside the kernel
-  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, VA ? 256 : 512, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
+  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, 512, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
                             nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
