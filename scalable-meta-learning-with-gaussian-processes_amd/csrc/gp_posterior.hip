@@ -457,10 +457,20 @@ extern "C" __global__ void scaml_target_finish_kernel(const double* __restrict__
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M) return;
   double a = mean_q[q], v = var_q[q];
-  for (int i = 0; i < n; ++i) {
-    const double k = Knq[(size_t)i * M + q];
-    a = __builtin_fma(k, alpha[i], a);
-    v = __builtin_fma(-k, Z[(size_t)i * M + q], v);
+  // (eight rows' loads in flight: one at a time, 2 n dependent round trips made this 26 us at n = 80)
+  for (int i0 = 0; i0 < n; i0 += 8) {
+    double k[8], z[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = i0 + u < n;
+      k[u] = ok ? Knq[(size_t)(i0 + u) * M + q] : 0.0;
+      z[u] = ok ? Z[(size_t)(i0 + u) * M + q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a = __builtin_fma(k[u], i0 + u < n ? alpha[i0 + u] : 0.0, a);
+      v = __builtin_fma(-k[u], z[u], v);
+    }
   }
   mu[q] = __builtin_fma(s_all, a, m_all);
   var[q] = s_all * s_all * (v + noise_add);
