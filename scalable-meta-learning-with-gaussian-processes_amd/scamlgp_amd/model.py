@@ -511,9 +511,27 @@ class ScaMLGP:
         self.covar_module._p.raw = v[D].clone()
         self.likelihood._p.raw = v[D + 1].clone()
 
+    def _param_tensors(self):
+        cov, lik = self.covar_module, self.likelihood
+        return (cov.base_kernel.raw_lengthscale, cov.raw_outputscale, lik.raw_noise)
+
+    @staticmethod
+    def _same_tensors(held, now) -> bool:
+        """True if `now` are the very tensors `held` was computed from, unmodified since ((tensor, version) pairs: the held
+        references keep the objects alive, so identity cannot be faked by a recycled address)."""
+        return held is not None and len(held) == len(now) and all(h is t and v == t._version for (h, v), t in zip(held, now))
+
     @property
     def theta(self) -> torch.Tensor:
-        return self.spec.to_theta(self.raw_theta)
+        """Constrained target hyper-parameters [lengthscales, outputscale, noise].  Cached per parameter state: an acquisition
+        pass asks for them (and for the pruned weights below) on every call, each time a dozen element-wise launches for the
+        same numbers -- a quarter of a scoring pass at configs[4] was such glue."""
+        now = self._param_tensors()
+        c = getattr(self, "_theta_cache", None)
+        if c is None or not self._same_tensors(c[0], now):
+            c = (tuple((t, t._version) for t in now), self.spec.to_theta(self.raw_theta))
+            self._theta_cache = c
+        return c[1]
 
     def train(self):
         self.training = True
@@ -539,6 +557,10 @@ class ScaMLGP:
         """Pruned weights as vectors over this rank's stack: w_full (T_stack,), active mask (bool)
         (scamlgp/model.py:365-372; the mask is decided on ALL T weights, each rank then takes its slice)."""
         w = self.weights
+        c = getattr(self, "_active_cache", None)
+        if c is not None and self._same_tensors(c[0], (w,)):
+            return c[1], c[2]      # (same weights as last time: see `theta`)
+        held = ((w, w._version),)
         mask = significant_weights_mask(w, self._std_source_stds(), self._weight_pruning_threshold)
         if self._shard is not None:
             w, mask = w[self._shard.local], mask[self._shard.local]
@@ -547,6 +569,7 @@ class ScaMLGP:
         idx = self._idx_dev
         w_full = torch.zeros(self._stack.T, dtype=torch.float64, device=self.device).scatter(0, idx, w)
         active = torch.zeros(self._stack.T, dtype=torch.bool, device=self.device).scatter(0, idx, mask)
+        self._active_cache = (held, w_full, active)
         return w_full, active
 
     def _source_prior(self, x: torch.Tensor, cov_first: int):

@@ -217,3 +217,44 @@ def test_graphed_acquisition_replays_match_eager(fitted, device):
             X = torch.rand(50, 2, dtype=torch.float64, generator=g)
             torch.testing.assert_close(ga(X), af(X), rtol=1e-12, atol=1e-14)
         assert ga(X[:7]).shape == (7,)   # another batch size falls back to the eager path
+
+
+def test_parameter_caches_follow_every_kind_of_parameter_change(fitted, device):
+    """`theta` and the pruned weights are cached per parameter state (an acquisition pass asks for them on every call): a new
+    tensor, an in-place update and a load_state_dict each have to show in the next posterior."""
+    meta, d, gps = fitted
+    g = torch.Generator().manual_seed(5)
+    Xt = torch.rand(6, 2, dtype=torch.float64, generator=g)
+    Yt = (torch.sin(4.0 * Xt[:, :1]) + Xt[:, 1:] ** 2) * 30.0 + torch.rand(6, 1, dtype=torch.float64, generator=g)
+    model = M.ScaMLGP(Xt, Yt, gps).eval()
+    xq = torch.rand(9, 2, dtype=torch.float64, generator=g)
+
+    def fresh(m):   # the same state in a model that has never cached anything
+        twin = M.ScaMLGP(Xt, Yt, gps).eval()
+        twin.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+        return twin.posterior(xq)
+
+    def check():
+        a, b = model.posterior(xq), fresh(model)
+        torch.testing.assert_close(a.mean, b.mean, rtol=1e-11, atol=1e-12)
+        torch.testing.assert_close(a.variance, b.variance, rtol=1e-10, atol=1e-13)
+
+    p0 = model.posterior(xq)
+    th0 = model.theta.clone()
+    assert model.theta is model.theta                       # served from the cache
+    check()
+    model.raw_theta = model.raw_theta + 0.3                 # new tensors
+    assert float((model.theta - th0).abs().max()) > 1e-3
+    check()
+    model.likelihood.raw_noise.add_(0.5)                    # in place
+    model.covar_module.base_kernel.raw_lengthscale.mul_(0.9)
+    check()
+    model.raw_weights.mul_(0.5)                             # in place: the pruning mask and the scattered weights
+    check()
+    model.weights = torch.full_like(model.raw_weights, 1e-6)   # everything pruned but for the threshold logic
+    check()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.raw_theta = model.raw_theta - 1.0
+    model.load_state_dict(sd)
+    check()
+    assert float((model.posterior(xq).mean - p0.mean).abs().max()) > 0.0
