@@ -234,7 +234,9 @@ int scaml_posterior_linv_cov_f64(const double* Xq, const double* X, const double
  *                               resid = y~ - (mean_s[:n] - m) / s,  mean_q = (mean_s[n:] - m) / s,  var_q = var_s[n:] / s^2 + os_t
  *   scaml_potrf_batched_f64     (T = 1) L L^T = Knn with psd_safe_cholesky's jitter ladder, alpha = Knn^-1 resid
  *   scaml_cho_solve_batched_f64 (T = 1, R = M) Z = Knn^-1 Knq
- *   scaml_target_finish_f64     mu[q] = m + s (mean_q + Knq[:, q] . alpha),  var[q] = s^2 (var_q - Knq[:, q] . Z[:, q] + noise_add)
+ *   scaml_target_finish_f64     mu[q] = m + s (mean_q + Knq[:, q] . alpha),  var[q] = s^2 (var_q - Knq[:, q] . Z[:, q] + noise_add);
+ *                               `info` (1) int32 or NULL: the POTRF's status -- a factorisation that failed even with jitter
+ *                               (psd_safe_cholesky would raise NotPSDError) turns every output into NaN on the device
  * Inputs: cov_s (n, n + M), mean_s (n + M), var_s (n + M) from (6') at cat(train_X, Xq); Xall (n + M, D) = cat(train_X, Xq);
  * theta (D + 2) of the TARGET kernel; train_targets (n) standardised with (m_all, s_all).  n >= 1.
  */
@@ -242,7 +244,8 @@ int scaml_target_assemble_f64(const double* cov_s, const double* mean_s, const d
                               const double* theta, const double* train_targets, double m_all, double s_all, int n, int M, int D,
                               int kind, double* Knn, double* resid, double* Knq, double* mean_q, double* var_q, void* stream);
 int scaml_target_finish_f64(const double* Knq, const double* Z, const double* alpha, const double* mean_q, const double* var_q,
-                            double m_all, double s_all, double noise_add, int n, int M, double* mu, double* var, void* stream);
+                            double m_all, double s_all, double noise_add, const int32_t* info, int n, int M, double* mu, double* var,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -453,9 +453,14 @@ template __global__ void scaml_target_assemble_kernel<1>(scaml::TargetAssemblePa
 extern "C" __global__ void scaml_target_finish_kernel(const double* __restrict__ Knq, const double* __restrict__ Z,
                                                       const double* __restrict__ alpha, const double* __restrict__ mean_q,
                                                       const double* __restrict__ var_q, double m_all, double s_all,
-                                                      double noise_add, int n, int M, double* __restrict__ mu, double* __restrict__ var) {
+                                                      double noise_add, const int32_t* __restrict__ info, int n, int M,
+                                                      double* __restrict__ mu, double* __restrict__ var) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M) return;
+  if (info && info[0] > 0) {   // not positive definite even with jitter: NaN, like the exception the reference would raise
+    mu[q] = var[q] = __builtin_nan("");
+    return;
+  }
   double a = mean_q[q], v = var_q[q];
   // (eight rows' loads in flight: one at a time, 2 n dependent round trips made this 26 us at n = 80)
   for (int i0 = 0; i0 < n; i0 += 8) {

@@ -666,7 +666,8 @@ int scaml_target_assemble_f64(const double* cov_s, const double* mean_s, const d
 }
 
 int scaml_target_finish_f64(const double* Knq, const double* Z, const double* alpha, const double* mean_q, const double* var_q,
-                            double m_all, double s_all, double noise_add, int n, int M, double* mu, double* var, void* stream) {
+                            double m_all, double s_all, double noise_add, const int32_t* info, int n, int M, double* mu, double* var,
+                            void* stream) {
   if (n < 1 || M < 0) return SCAML_E_BADARG;
   if (M == 0) return SCAML_OK;
   if (!Knq || !Z || !alpha || !mean_q || !var_q || !mu || !var) return SCAML_E_BADARG;
@@ -674,7 +675,7 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   void* args[] = {(void*)&Knq, (void*)&Z, (void*)&alpha, (void*)&mean_q, (void*)&var_q, (void*)&m_all, (void*)&s_all, (void*)&noise_add,
-                  (void*)&n, (void*)&M, (void*)&mu, (void*)&var};
+                  (void*)&info, (void*)&n, (void*)&M, (void*)&mu, (void*)&var};
   e = hipModuleLaunchKernel(m.tgt_finish, (unsigned)((M + 127) / 128), 1, 1, 128, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_finish)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;

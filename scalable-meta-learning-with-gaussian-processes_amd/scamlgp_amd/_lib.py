@@ -116,7 +116,7 @@ def _load() -> ctypes.CDLL:
     lib.scaml_target_assemble_f64.restype = c_int
     lib.scaml_target_assemble_f64.argtypes = [_dp] * 6 + [c_double, c_double, c_int, c_int, c_int, c_int] + [_dp] * 5 + [c_void_p]
     lib.scaml_target_finish_f64.restype = c_int
-    lib.scaml_target_finish_f64.argtypes = [_dp] * 5 + [c_double, c_double, c_double, c_int, c_int, _dp, _dp, c_void_p]
+    lib.scaml_target_finish_f64.argtypes = [_dp] * 5 + [c_double, c_double, c_double, _dp, c_int, c_int, _dp, _dp, c_void_p]
     lib.scaml_debug_force_two_launch_grad.restype = c_int
     lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib

@@ -645,10 +645,8 @@ class ScaMLGP:
             mu_s, cov_s, var_s = self._source_prior(xall, n)
             mu_o, var_o, info, _ = ops.target_posterior(cov_s, mu_s, var_s, xall, self.theta, self.train_targets, self._m_all_f,
                                                          self._s_all_f, self.kind, observation_noise)
-            # a factorisation that fails even with jitter (psd_safe_cholesky would raise NotPSDError) shows as NaN here:
-            # the status stays on the device so that an acquisition-function evaluation never waits for the host
-            bad = torch.where(info > 0, float("nan"), 0.0).to(torch.float64)   # (1,): NaN marks a failed factorisation
-            mu_o, var_o = mu_o + bad, var_o + bad
+            # (a factorisation that fails even with jitter -- psd_safe_cholesky would raise NotPSDError -- comes back as NaN: the status
+            #  stays on the device so that an acquisition-function evaluation never waits for the host)
         else:
             mean, cov, var_q, theta = self._joint(Xq, full=False)
             if n == 0:

@@ -454,7 +454,8 @@ def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Ten
     """Posterior mean / variance (original units) of the ScaML-GP target GP at the M query points behind the n training
     points in ``Xall`` (n + M, D), from the weighted source sums at the same points: cov_s (n, n + M), mean_s, var_s
     (n + M).  scaml_target_assemble_f64 -> scaml_potrf_batched_f64 (T = 1, jitter ladder) -> scaml_cho_solve_batched_f64
-    -> scaml_target_finish_f64: four launches, no host synchronisation.  Returns (mu (M,), var (M,), info (1,), jitter (1,))."""
+    -> scaml_target_finish_f64: four launches, no host synchronisation.  A factorisation that fails even with jitter shows as NaN
+    in mu / var (the status stays on the device).  Returns (mu (M,), var (M,), info (1,), jitter (1,))."""
     n = int(train_targets.shape[0])
     W, D = Xall.shape
     M = W - n
@@ -480,7 +481,8 @@ def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Ten
         if M > 0:
             Z = cho_solve(f["L"], f["Linv_diag"], Knq)
             rc = _lib.lib.scaml_target_finish_f64(_ptr(Knq), _ptr(Z), _ptr(f["alpha"]), _ptr(mean_q), _ptr(var_q), float(m_all), float(s_all),
-                                                  float(theta[D + 1]) if observation_noise else 0.0, n, M, _ptr(mu), _ptr(var), _stream_handle())
+                                                  float(theta[D + 1]) if observation_noise else 0.0, _ptr(f["info"]), n, M, _ptr(mu), _ptr(var),
+                                                  _stream_handle())
             _lib.check_rc(rc, "scaml_target_finish_f64")
     return mu, var, f["info"], f["jitter"]
 

@@ -258,3 +258,24 @@ def test_parameter_caches_follow_every_kind_of_parameter_change(fitted, device):
     model.load_state_dict(sd)
     check()
     assert float((model.posterior(xq).mean - p0.mean).abs().max()) > 0.0
+
+
+def test_target_posterior_marks_a_failed_factorisation_with_nan_on_the_device(device):
+    """The target GP's Cholesky failing even with jitter (psd_safe_cholesky would raise NotPSDError) must not go unnoticed and
+    must not cost a host synchronisation: scaml_target_finish_f64 turns the outputs into NaN from the status word."""
+    from scamlgp_amd import ops
+    g = torch.Generator().manual_seed(0)
+    n, Mq, D = 12, 7, 2
+    xall = torch.rand(n + Mq, D, dtype=torch.float64, generator=g)
+    xall[1] = xall[0]                                           # duplicate training points
+    zeros = torch.zeros(n, n + Mq, dtype=torch.float64)
+    vec = torch.zeros(n + Mq, dtype=torch.float64)
+    y = torch.randn(n, dtype=torch.float64, generator=g)
+    for noise, ok in ((1e-3, True), (-1e-3, False)):            # a negative "noise" no jitter of the ladder can repair
+        theta = torch.tensor([0.5, 0.5, 1.0, noise], dtype=torch.float64)
+        mu, var, info, _ = ops.target_posterior(zeros.to(device), vec.to(device), vec.to(device), xall.to(device), theta.to(device), y.to(device),
+                                                0.0, 1.0, O.KIND_RBF)
+        assert (int(info[0]) == 0) == ok
+        assert bool(torch.isfinite(mu).all()) == ok and bool(torch.isfinite(var).all()) == ok
+        if not ok:
+            assert bool(torch.isnan(mu).all()) and bool(torch.isnan(var).all())
