@@ -610,9 +610,15 @@ class ScaMLGP:
         mean = (self.source_means @ w - self.m_all) / self.s_all
         cov = (self.source_covs @ w ** 2) / self.s_all ** 2 + _kernel_torch(self.train_X, self.train_X, theta, self.kind)
         cov = cov + theta[-1] * torch.eye(self.n, dtype=torch.float64, device=self.device)
-        Lc = psd_safe_cholesky(cov)
-        v = torch.linalg.solve_triangular(Lc, (self.train_targets - mean).unsqueeze(-1), upper=False)
-        val = -0.5 * ((v * v).sum() + 2.0 * torch.log(torch.diagonal(Lc)).sum() + self.n * _LOG_2PI)
+        if 1 <= self.n <= ops.fit_max_n():
+            # the library's jittered Cholesky + solves as ONE differentiable op: no host synchronisation (psd_safe_cholesky's
+            # status check is one), so that the whole objective can be replayed from a HIP graph (utils._fit_target); a matrix
+            # that is not positive definite even with jitter gives NaN instead of NotPSDError
+            val = ops.gaussian_log_prob(cov, self.train_targets - mean)
+        else:
+            Lc = psd_safe_cholesky(cov)
+            v = torch.linalg.solve_triangular(Lc, (self.train_targets - mean).unsqueeze(-1), upper=False)
+            val = -0.5 * ((v * v).sum() + 2.0 * torch.log(torch.diagonal(Lc)).sum() + self.n * _LOG_2PI)
         val = val + self.spec.log_prior(theta) + self.weights_prior.log_prob(w).sum()
         return val / self.n
 

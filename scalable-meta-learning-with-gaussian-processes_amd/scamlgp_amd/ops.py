@@ -568,6 +568,43 @@ class FusedMLL(torch.autograd.Function):
         return None, None, g * grad_mll.unsqueeze(-1), None, None, None
 
 
+class GaussianLogProb(torch.autograd.Function):
+    """log N(resid | 0, K) for ONE given covariance matrix K (n, n), n <= scaml_fit_max_n(), as a differentiable torch op on the
+    library's launches: forward = scaml_potrf_batched_f64 (T = 1; psd_safe_cholesky's jitter ladder in-kernel, alpha, quad, logdet),
+    backward = scaml_cho_solve_batched_f64 with the identity as right-hand side (K^-1), d/dK = (alpha alpha^T - K^-1) / 2,
+    d/dresid = -alpha.  This is the MultivariateNormal.log_prob of the TARGET GP's marginal likelihood
+    (scamlgp/utils.py:171-177 on the ScaMLGP model of scamlgp/model.py:359-384), whose K is not a kernel matrix of points but
+    weighted source covariances + target kernel + noise.  Nothing synchronises with the host: a factorisation that fails even
+    with jitter gives NaN (value and gradient), and the status of the last call is in ``GaussianLogProb.last_info``."""
+
+    last_info: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def forward(ctx, K, resid):
+        n = K.shape[-1]
+        f = potrf_batched(K.detach().reshape(1, n, n).contiguous(), resid.detach().reshape(1, n).contiguous(), want_linv=True)
+        GaussianLogProb.last_info = f["info"]
+        ctx.save_for_backward(f["L"], f["Linv_diag"], f["alpha"], f["info"])
+        nan = torch.where(f["info"] > 0, float("nan"), 0.0).to(torch.float64)
+        return (-0.5 * (f["quad"] + f["logdet"] + n * 1.8378770664093453) + nan).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        L, W, alpha, info = ctx.saved_tensors
+        n = L.shape[-1]
+        eye = torch.eye(n, dtype=torch.float64, device=L.device).unsqueeze(0)
+        Kinv = cho_solve(L, W, eye)[0]
+        a = alpha[0]
+        nan = torch.where(info > 0, float("nan"), 0.0).to(torch.float64)
+        gK = 0.5 * (torch.outer(a, a) - Kinv) + nan
+        return g * gK, g * (-a + nan)
+
+
+def gaussian_log_prob(K: torch.Tensor, resid: torch.Tensor) -> torch.Tensor:
+    """Functional form of ``GaussianLogProb``."""
+    return GaussianLogProb.apply(K, resid)
+
+
 def fused_mll(X: torch.Tensor, y: torch.Tensor, theta: torch.Tensor, kind: int,
               n_points: Optional[torch.Tensor] = None, out: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """Functional form of ``FusedMLL``.  ``out`` (the dict ``FusedMLL.last`` of an earlier call with the same shapes)

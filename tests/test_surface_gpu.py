@@ -198,3 +198,66 @@ def test_shuffled_meta_data_give_the_same_model(device):
     model_o = M.ScaMLGP(xt, yt, M.meta_fit_scamlgp(other, num_restarts_log_likelihood=0, seed=1))
     mo = model_o.eval().posterior(xq).mvn.mean.cpu()
     assert float((mo - m0).abs().max()) > 1e-2 * float(m0.abs().max())
+
+
+def test_gaussian_log_prob_op_matches_torch_and_gradcheck(device):
+    """ops.GaussianLogProb (the target GP's MultivariateNormal.log_prob on the library's factorisation): value and both
+    gradients against torch.distributions, finite-difference gradcheck, NaN for a matrix no jitter repairs."""
+    from scamlgp_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 33, 80, 200):
+        A = torch.randn(n, n, dtype=torch.float64, generator=g)
+        K0 = (A @ A.T / n + 0.5 * torch.eye(n, dtype=torch.float64))
+        r0 = torch.randn(n, dtype=torch.float64, generator=g)
+        K = K0.to(device).requires_grad_(True)
+        r = r0.to(device).requires_grad_(True)
+        val = ops.gaussian_log_prob(K, r)
+        gK, gr = torch.autograd.grad(val, (K, r))
+        Kc, rc = K0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        ref = torch.distributions.MultivariateNormal(torch.zeros(n, dtype=torch.float64), covariance_matrix=Kc).log_prob(rc)
+        hK, hr = torch.autograd.grad(ref, (Kc, rc))
+        torch.testing.assert_close(val.cpu(), ref.detach(), rtol=1e-10, atol=1e-10)
+        torch.testing.assert_close(gr.cpu(), hr, rtol=1e-8, atol=1e-10)
+        # torch differentiates through the lower triangle only: compare the symmetrised gradients
+        torch.testing.assert_close(0.5 * (gK + gK.T).cpu(), 0.5 * (hK + hK.T), rtol=1e-7, atol=1e-9)
+    n = 6
+    A = torch.randn(n, n, dtype=torch.float64, generator=g)
+    K = (A @ A.T + torch.eye(n, dtype=torch.float64)).to(device).requires_grad_(True)
+    r = torch.randn(n, dtype=torch.float64, generator=g).to(device).requires_grad_(True)
+    sym = lambda K_, r_: ops.gaussian_log_prob(0.5 * (K_ + K_.T), r_)
+    assert torch.autograd.gradcheck(sym, (K, r), eps=1e-6, atol=1e-6, rtol=1e-5)
+    bad = -torch.eye(4, dtype=torch.float64, device=device).requires_grad_(True)
+    v = ops.gaussian_log_prob(bad, torch.ones(4, dtype=torch.float64, device=device))
+    (gb,) = torch.autograd.grad(v, bad)
+    assert bool(torch.isnan(v)) and bool(torch.isnan(gb).all()) and int(ops.GaussianLogProb.last_info[0]) > 0
+
+
+def test_target_objective_replayed_from_a_hip_graph_equals_the_eager_one(device):
+    """utils._GraphedObjective: forward + autograd backward of -mll(z) captured once; every replay gives the eager numbers bit for
+    bit, and the fit through it ends where the eager fit ends."""
+    from scamlgp_amd.utils import _GraphedObjective, _fit_target
+    d = synthetic.branin_task_stack(4, 24, seed=2, noise_std=1.0)
+    meta = {f"t{t}": M.SupervisedDataset(torch.from_numpy(d["X"][t]), torch.from_numpy(d["Y"][t]).unsqueeze(-1)) for t in range(4)}
+    gps = M.meta_fit_scamlgp(meta, num_restarts_log_likelihood=0, seed=3)
+    g = torch.Generator().manual_seed(11)
+    Xt = torch.rand(9, 2, dtype=torch.float64, generator=g)
+    Yt = (torch.sin(5.0 * Xt[:, :1]) + Xt[:, 1:]) * 20.0
+    model = M.ScaMLGP(Xt, Yt, gps)
+    D2 = model.raw_theta.numel()
+    gobj = _GraphedObjective(model, D2)
+    assert gobj.ok
+    z0 = torch.cat([model.raw_theta, model.raw_weights]).cpu().numpy()
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        z = z0 + 0.2 * rng.standard_normal(z0.shape)
+        z[D2:] = np.abs(z[D2:]) + 1e-3
+        zt = torch.tensor(z, dtype=torch.float64, device=device, requires_grad=True)
+        val = -model.mll(zt[:D2], zt[D2:])
+        (gr,) = torch.autograd.grad(val, zt)
+        out = gobj(z).copy()
+        assert out[0] == float(val.detach()) and np.array_equal(out[1:], gr.cpu().numpy())
+    a, b = M.ScaMLGP(Xt, Yt, gps), M.ScaMLGP(Xt, Yt, gps)
+    torch.manual_seed(5); _fit_target(a, num_restarts=1, use_graph=True)
+    torch.manual_seed(5); _fit_target(b, num_restarts=1, use_graph=False)
+    torch.testing.assert_close(a.raw_theta, b.raw_theta, rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(a.raw_weights, b.raw_weights, rtol=1e-9, atol=1e-9)
