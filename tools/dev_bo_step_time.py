@@ -1,0 +1,25 @@
+"""Wall time of one BO step at configs[4] shapes (T = 32 sources of 512 points, Hartmann-6): report() = refit of the target GP,
+suggest() = acquisition optimisation (EI), with the per-part breakdown."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scalable-meta-learning-with-gaussian-processes_amd")); sys.path.insert(0, ROOT)
+import numpy as np, torch
+from scamlgp_amd import model as M, synthetic, utils
+from scamlgp_amd.bo import ScaMLGPBOLoop
+T, N = 32, 512
+d = synthetic.hartmann6_task_stack(T, N, seed=0)
+st = M.SourceGPStack(list(range(T)), [torch.from_numpy(d["X"][t]) for t in range(T)], [torch.from_numpy(d["Y"][t]).unsqueeze(-1) for t in range(T)], kind=1)
+t0 = time.perf_counter(); utils._fit_stack(st, num_restarts=1, max_iter=30); torch.cuda.synchronize()
+print(f"meta-fit (2 starts x 30 iterations): {time.perf_counter() - t0:.2f} s")
+gps = {tid: M.SourceGP(st, i) for i, tid in enumerate(st.task_ids)}
+obj = lambda x: float(synthetic.hartmann6(np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
+loop = ScaMLGPBOLoop(gps, dim=6, acquisition="ei", num_restarts_log_likelihood=2, seed=0)
+g = torch.Generator().manual_seed(1)
+for i in range(20):   # 20 points of history
+    x = torch.rand(6, dtype=torch.float64, generator=g)
+    loop.X = x.unsqueeze(0) if loop.X is None or len(loop.X) == 0 else torch.cat([loop.X, x.unsqueeze(0)])
+    loop.Y = torch.tensor([[obj(x)]], dtype=torch.float64) if loop.Y is None or len(loop.Y) == 0 else torch.cat([loop.Y, torch.tensor([[obj(x)]], dtype=torch.float64)])
+for step in range(3):
+    t0 = time.perf_counter(); x = loop.suggest(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    loop.report(x, obj(x)); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"step {step}: suggest {t1 - t0:.3f} s, report (refit) {t2 - t1:.3f} s, n = {loop.model.n}")
