@@ -139,3 +139,30 @@ def test_more_dimensions_than_threads(device, N, D):
             for p in (post, post2):
                 torch.testing.assert_close(p["mean"][t].cpu(), mu, rtol=1e-4, atol=1e-4 * float(mu.abs().max()))
                 torch.testing.assert_close(p["var"][t].cpu(), torch.diagonal(cov), rtol=1e-4, atol=1e-4 * float(cov.abs().max()))
+
+
+def test_posterior_expanded_distance_under_cancellation(device):
+    """The L^-1 posterior pass takes the squared distances of a block off the matrix core in the expanded form (round 2): short
+    lengthscales and query points (almost) on top of training points are where that form loses digits.  Held to north_star's
+    1e-4 on mean / variance against the oracle's difference form, with and without the fused covariance block."""
+    T, N, D, M = 3, 96, 8, 40
+    g = torch.Generator().manual_seed(8)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g)
+    y = torch.randn(T, N, dtype=torch.float64, generator=g)
+    Xq = torch.rand(M, D, dtype=torch.float64, generator=g)
+    Xq[:10] = X[0, :10] + 1e-6          # near-duplicates of training points of task 0
+    Xq[10:14] = X[1, 5:9]               # exact duplicates (task 1)
+    Xq[14] = Xq[15] + 1e-7              # two queries almost on top of each other
+    for ls in (0.02, 0.2):
+        theta = torch.cat([torch.full((T, D), ls), torch.ones(T, 1), torch.full((T, 1), 1e-3)], 1).double()
+        for kind in (O.KIND_MATERN52, O.KIND_RBF):
+            fit = ops.gp_fit_fused(X.to(device), y.to(device), theta.to(device), kind, want_linv=True)
+            Linv = ops.linv_batched(fit["L"], fit["Linv_diag"])
+            post = ops.source_posteriors(Xq.to(device), X.to(device), theta.to(device), kind, None, None, fit["alpha"], Linv=Linv, cov_first=16)
+            for t in range(T):
+                ref = O.gp_fit(X[t], y[t], theta[t], kind, dist="direct")
+                mu, cov = O.source_posterior(Xq, X[t], theta[t], kind, ref["L"], ref["alpha"], 0.0, 1.0)
+                var = torch.diagonal(cov)
+                torch.testing.assert_close(post["mean"][t].cpu(), mu, rtol=1e-4, atol=1e-4 * float(mu.abs().max()))
+                torch.testing.assert_close(post["var"][t].cpu(), var, rtol=1e-4, atol=1e-4 * float(var.abs().max()))
+                torch.testing.assert_close(post["cov"][t].cpu(), cov[:16], rtol=1e-4, atol=1e-4 * float(cov.abs().max()))
