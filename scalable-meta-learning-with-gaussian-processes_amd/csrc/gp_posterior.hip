@@ -389,29 +389,36 @@ __global__ __launch_bounds__(256) void gp_posterior_cov_kernel(PosteriorCovParam
 
 }  // namespace scaml
 
-// out[e] = sum_t coef(t) * in[t][e], coef = w_t (power 1) or w_t^2 (power 2), skipping masked tasks
-extern "C" __global__ void scaml_weighted_task_sum_kernel(const double* __restrict__ in, const double* __restrict__ w,
-                                         const uint8_t* __restrict__ active, int T, long long len, int power,
-                                         double* __restrict__ out) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= len) return;
-  // eight tasks' values in flight per thread (one load at a time left the pass latency-bound: 17 us for the 23 MB of the
-  // configs[4] covariance block); the sum itself stays in task order
+// out[e] = sum_t coef(t) * in[t][e], coef = w_t (power 1) or w_t^2 (power 2), skipping masked tasks.
+// A workgroup of 256 threads takes 64 consecutive elements; wave q sums the q-th quarter of the tasks (eight tasks' values in flight per
+// thread), the four partial sums meet in LDS in a fixed order: 4 x the waves in flight of one-thread-per-element (the pass is a pure
+// stream of T len doubles: 23 MB at configs[4] took 17 us with one load in flight per thread, ~5 us now), deterministic.
+extern "C" __global__ __launch_bounds__(256) void scaml_weighted_task_sum_kernel(const double* __restrict__ in, const double* __restrict__ w,
+                                                                              const uint8_t* __restrict__ active, int T, long long len, int power,
+                                                                              double* __restrict__ out) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  const int chunk = (T + 3) / 4, t_lo = q * chunk, t_hi = t_lo + chunk < T ? t_lo + chunk : T;
   double s = 0.0;
-  for (int t0 = 0; t0 < T; t0 += 8) {
-    double v[8], c[8];
+  if (e < len) {
+    for (int t0 = t_lo; t0 < t_hi; t0 += 8) {
+      double v[8], c[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int t = t0 + k;
-      const bool ok = t < T && (!active || active[t]);   // (a masked task is skipped, not multiplied by zero: its values may be NaN)
-      v[k] = ok ? in[(size_t)t * len + e] : 0.0;
-      const double wt = ok ? w[t] : 0.0;
-      c[k] = power == 2 ? wt * wt : wt;
+      for (int k = 0; k < 8; ++k) {
+        const int t = t0 + k;
+        const bool ok = t < t_hi && (!active || active[t]);   // (a masked task is skipped, not multiplied by zero: its values may be NaN)
+        v[k] = ok ? in[(size_t)t * len + e] : 0.0;
+        const double wt = ok ? w[t] : 0.0;
+        c[k] = power == 2 ? wt * wt : wt;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s = __builtin_fma(c[k], v[k], s);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s = __builtin_fma(c[k], v[k], s);
   }
-  out[e] = s;
+  part[q][lane] = s;
+  __syncthreads();
+  if (q == 0 && e < len) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 // ---- target GP (scamlgp/model.py:359-384 eval branch + gpytorch's exact prediction) ------------------

@@ -429,7 +429,7 @@ int scaml_weighted_task_sum_f64(const double* in, const double* w, const uint8_t
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   void* args[] = {(void*)&in, (void*)&w, (void*)&active, (void*)&T, (void*)&len, (void*)&power, (void*)&out};
-  e = hipModuleLaunchKernel(m.wsum, (unsigned)((len + 255) / 256), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+  e = hipModuleLaunchKernel(m.wsum, (unsigned)((len + 63) / 64), 1, 1, 256, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(weighted_task_sum)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
