@@ -24,7 +24,7 @@ namespace {
 
 thread_local char g_last_error[256] = "";
 bool g_no_grad_split = getenv("SCAML_GRAD_NO_SPLIT") != nullptr;              // developer A/B switch
-bool g_force_two_launch_grad = getenv("SCAML_GRAD_LEGACY") != nullptr;   // developer A/B switch (scaml_debug_force_two_launch_grad)
+int g_grad_path = getenv("SCAML_GRAD_LEGACY") ? 1 : (getenv("SCAML_GRAD_FUSED") ? 2 : 0);   // 0 by shape, 1 two launches, 2 single launch (scaml_debug_force_two_launch_grad)
 
 void set_error(const char* what, hipError_t e) {
   snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
@@ -598,7 +598,11 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
   double* partials = partials_out ? partials_out : workspace + (size_t)T * N * N;
   // N <= 256, D <= 8: ONE launch, one workgroup per task, K^-1 by column strips held in registers; neither L^-1 nor
   // K^-1 touches memory (csrc/gp_mll_grad_fused.hip).  Larger problems take the two-launch path below.
-  if (N <= 256 && D <= 8 && !g_force_two_launch_grad) {
+  // (measured, tools/dev_grad_select.py: a stack of at most 64 tasks of more than 64 points leaves most CUs idle with one
+  //  workgroup per task, and there the two launches below -- L^-1 strips and K^-1 tiles spread over the chip -- win: 96 vs 120 us at
+  //  T = 32, N = 256; 44 vs 49 us at T = 64, N = 128)
+  const bool small_stack = N > 64 && T <= 64;
+  if (N <= 256 && D <= 8 && g_grad_path != 1 && !(small_stack && g_grad_path != 2 && !g_no_grad_split)) {
     const int sc = N <= 32 ? 0 : (N <= 64 ? 1 : (N <= 128 ? 2 : 3));
     const int nbt = 2 << sc, np = 16 * nbt, nw = nbt / 2;
     const size_t lds = ((size_t)2 * 16 * (np + 2) + (size_t)2 * np * 9 + 16 + np + (size_t)nw * 512 + 64 + 8 + (size_t)nw * 10) * sizeof(double);
@@ -614,11 +618,10 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.num_cus = cus;
       if (m.num_cus <= 0) m.num_cus = 256;
     }
+    // (split tasks pay for themselves in the N <= 256 class between 65 and 128 tasks only: 100 vs 105 us at T = 128; in the N <= 128
+    //  class every split measured slower than one workgroup per task: 57 vs 49 us at T = 64)
     int split = 1;
-    if (sc >= 2 && dma && !g_no_grad_split) {
-      if (4 * T <= m.num_cus) split = 4;
-      else if (2 * T <= m.num_cus) split = 2;
-    }
+    if (sc == 3 && dma && !g_no_grad_split && 2 * T <= m.num_cus) split = 2;
     hipFunction_t fn = split == 1 ? m.mllgrad_fused[sc][kind][dma] : m.mllgrad_split[sc - 2][split == 2 ? 0 : 1][kind];
     e = hipModuleLaunchKernel(fn, (unsigned)T, (unsigned)split, 1, (unsigned)(nbt * 32 / split), 1, 1, (unsigned)lds, (hipStream_t)stream,
                               nullptr, config);
@@ -681,11 +684,12 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
   return SCAML_OK;
 }
 
-// Developer switch: route scaml_mll_backward_f64 through the two-launch path (L^-1 in the workspace, then the K^-1 tile
-// kernel) even where the single-launch kernel applies -- for A/B timing and for testing one path against the other.
-int scaml_debug_force_two_launch_grad(int on) {
-  const int was = g_force_two_launch_grad ? 1 : 0;
-  g_force_two_launch_grad = on != 0;
+// Developer switch: 1 routes scaml_mll_backward_f64 through the two-launch path (L^-1 in the workspace, then the K^-1 tile kernel)
+// even where the single-launch kernel applies, 2 through the single-launch kernel even for the small stacks the two launches serve
+// by default, 0 restores the choice by shape -- for A/B timing and for testing one path against the other.  Returns the previous mode.
+int scaml_debug_force_two_launch_grad(int mode) {
+  const int was = g_grad_path;
+  g_grad_path = mode == 1 ? 1 : (mode == 2 ? 2 : 0);
   return was;
 }
 

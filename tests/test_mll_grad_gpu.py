@@ -54,13 +54,21 @@ def test_mll_gradient_matches_autograd(T, N, D, kind, device):
         ref = _autograd_grad(X[t], y[t], theta[t], kind)
         # gradient entries span orders of magnitude (the noise derivative is ~1e3 larger): compare per entry
         torch.testing.assert_close(g[t], ref, rtol=1e-6, atol=1e-9 * float(ref.abs().max()))
-    # the single-launch kernel (N <= 256, D <= 8) and the two-launch path (L^-1 in memory) agree
+    # the single-launch kernel (N <= 256, D <= 8) and the two-launch path (L^-1 in memory) agree -- both forced: by shape the library
+    # sends stacks of at most 64 tasks of more than 64 points through the two launches
     from scamlgp_amd import _lib
-    was = _lib.lib.scaml_debug_force_two_launch_grad(1)
+    Lc = torch.tril(torch.nan_to_num(fit["L"]))
+    was = _lib.lib.scaml_debug_force_two_launch_grad(2)
     try:
-        g2 = ops.mll_backward(X.to(device), theta.to(device), kind, torch.tril(torch.nan_to_num(fit["L"])), fit["Linv_diag"], fit["alpha"]).cpu()
+        g1 = ops.mll_backward(X.to(device), theta.to(device), kind, fit["L"], fit["Linv_diag"], fit["alpha"]).cpu()
+        _lib.lib.scaml_debug_force_two_launch_grad(1)
+        g2 = ops.mll_backward(X.to(device), theta.to(device), kind, Lc, fit["Linv_diag"], fit["alpha"]).cpu()
     finally:
         _lib.lib.scaml_debug_force_two_launch_grad(was)
+    for t in range(T):
+        ref = _autograd_grad(X[t], y[t], theta[t], kind)
+        torch.testing.assert_close(g1[t], ref, rtol=1e-6, atol=1e-9 * float(ref.abs().max()))
+    torch.testing.assert_close(g1, g2, rtol=1e-8, atol=1e-11 * float(g2.abs().max()))
     torch.testing.assert_close(g, g2, rtol=1e-8, atol=1e-11 * float(g2.abs().max()))
 
 
