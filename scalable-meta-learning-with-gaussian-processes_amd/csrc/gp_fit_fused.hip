@@ -531,13 +531,14 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     // wave.  With 7 update waves the panel wave therefore builds the last slots of the six update waves that
     // do not share its SIMD into LDS images, which their owners pick up after the barrier.  The second wave
     // of a SIMD (4, 5, 6) only gets the issue slots its older mate leaves (measured 3.0 k cycles per tile
-    // against 2.6 k; the panel wave 3.8 k), so it hands over three tiles (slots 16..18) and the first waves
-    // one (slot 19): 12 of the 136 tiles, and all waves finish within a few per cent of each other.
+    // against 2.6 k; the panel wave 3.8 k), so it hands over two tiles (slots 17, 18) and the first waves
+    // one (slot 19): 9 of the 136 tiles.  (Round 1: three and one, 12 tiles; re-tuned at the end of round 2 together with
+    // PSTORE below, after the panel loop had changed: 106.8 -> 105.3 us in interleaved A/B runs.)
     constexpr bool PANEL_BUILDS = (WU == 7 && NB == 16);
     constexpr int KMATE = 3;   // wave KMATE shares the panel wave's SIMD (waves go round-robin)
 #ifndef SCAML_KOLD
 #define SCAML_KOLD 19
-#define SCAML_KYOUNG 16
+#define SCAML_KYOUNG 17
 #endif
     auto kslot_of = [](int w) { return w < KMATE ? SCAML_KOLD : SCAML_KYOUNG; };
     double* KT = lds + XROWS * NP;   // [6][4][256] register images, behind xsT
@@ -637,9 +638,9 @@ __device__ __forceinline__ int gp_fit_attempt(const FitParams& p, const double j
     };
     // The first PSTORE columns go to HBM from the panel wave: in the early panels it runs a whole step ahead
     // of the update waves (which are the bottleneck there) and has the time; later it is the bottleneck
-    // itself and the update waves store their own tiles.
+    // itself and the update waves store their own tiles.  (8 columns: re-tuned at the end of round 2; it was 12.)
 #ifndef SCAML_PSTORE
-#define SCAML_PSTORE 12
+#define SCAML_PSTORE 8
 #endif
     constexpr int PSTORE = (WU == 7 && NB == 16) ? SCAML_PSTORE : 0;
 
