@@ -5,7 +5,7 @@
 //        [K21 K22] = [L21   L22] [      L22^T]      L21^T = L11^-1 K12, r2 = y2 - L21 v1       (gp_blocked_solve_kernel, 4 CUs / task)
 //                                                   S    = K22 + (noise + jitter) I - L21 L21^T (gp_blocked_syrk_kernel, 10 CUs / task)
 //                                                   L22  = chol(S), alpha2 = S^-1 r2, in place  (gp_fit_blocked_kernel on S)
-//                                                   alpha1 = L11^-T (v1 - L21^T alpha2), MLL    (gp_blocked_finish_kernel)
+//                                                   alpha1 = L11^-T (v1 - L21^T alpha2), MLL    (scaml_blocked_finish_kernel)
 // (v1 = L11^-1 y1: the first fit stops after its forward substitution, FIT_FORWARD_ONLY)
 //
 // The reference fits source GPs of up to 512 points (scamlgp/benchmarking/configurations/
@@ -13,8 +13,8 @@
 // cholesky_solve); a 512 x 512 task does not fit the registers + LDS of one CU, which is what the single-launch kernel
 // lives on.  The jitter ladder of psd_safe_cholesky (one jitter value for the whole matrix of a failing task) is kept
 // exact: every launch of a round is single-shot; the launches of rounds 1-3 are enqueued unconditionally, and
-// gp_blocked_round_kernel switches off (active[t] = 0) every task that is already factored, so that they cost an
-// empty launch each when nothing failed.
+// scaml_blocked_round_kernel switches off (active[t] = 0) every task that is already factored, so that they cost an
+// empty launch each (~2 us) when nothing failed.  Host side: scaml_gp_fit_blocked_f64 in csrc/scaml_host.cpp.
 #include "../../include/scaml_gp.h"
 #include "gf_tiles.hpp"
 #include "gp_fit_params.h"
