@@ -471,7 +471,26 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
   __shared__ double w[BK_N1];
   __shared__ double u[BK_N1];
   const int task = blockIdx.x, tid = threadIdx.x;
-  const int N = p.N;
+  const int N = p.N, N2 = N - BK_N1;
+  const double* Lg = p.L + (size_t)task * N * N;
+  const double* Wg = p.Linv_diag + (size_t)task * ((N + 15) / 16) * 256;
+  double* al = p.alpha + (size_t)task * N;
+  const int j = tid & 255, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
+  // Everything that depends on nothing but the task index starts its way FIRST (the kernel is a chain of memory round trips at one
+  // workgroup per task): the ring's first four block rows (15 .. 12), every W_kb, and the first 16 of this thread's 64 rows of
+  // L21 for the mat-vec (rows of L21 past n2 are zeros, written by the strip solve: no mask needed, only the matrix bound).
+  double ring[8][4];
+  bk_finish_load<15>(ring[7], Lg, N, q, j); bk_finish_load<14>(ring[6], Lg, N, q, j);
+  bk_finish_load<13>(ring[5], Lg, N, q, j); bk_finish_load<12>(ring[4], Lg, N, q, j);
+  double wl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wl[i] = Wg[tid + 1024 * i];
+  const int r0 = q * 64;
+  const double* col = Lg + (size_t)(BK_N1 + r0) * N + j;
+  double cv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) cv[k] = r0 + k < N2 ? col[(size_t)k * N] : 0.0;
   const int n1 = p.n1[task], n2 = p.n2[task], n = n1 + n2;
   const int i1 = p.info1[task], i2 = p.info2[task];
   const int info = i1 > 0 ? i1 : (i2 > 0 ? i2 + BK_N1 : 0);
@@ -479,40 +498,25 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
     p.info[task] = info;
     if (p.jitter_used) p.jitter_used[task] = p.jit_ladder[task];
     const double nan = __builtin_nan("");
-    const double q = p.q12[task] + p.q12[2 * p.T + task], ld = p.q12[p.T + task] + p.q12[3 * p.T + task];
-    if (p.quad) p.quad[task] = info ? nan : q;
+    const double qd = p.q12[task] + p.q12[2 * p.T + task], ld = p.q12[p.T + task] + p.q12[3 * p.T + task];
+    if (p.quad) p.quad[task] = info ? nan : qd;
     if (p.logdet) p.logdet[task] = info ? nan : ld;
-    if (p.mll) p.mll[task] = info ? nan : (n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0);
+    if (p.mll) p.mll[task] = info ? nan : (n > 0 ? -0.5 * (qd + ld + n * 1.8378770664093454836) / n : 0.0);
   }
   if (info) return;
   BK_STAMP_INIT(tid == 0);
-  const double* Lg = p.L + (size_t)task * N * N;
-  const double* Wg = p.Linv_diag + (size_t)task * ((N + 15) / 16) * 256;
-  double* al = p.alpha + (size_t)task * N;
-  const int j = tid & 255, lane = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 8);
-  // the ring's first eight block rows (15 .. 8) and every W_kb start their way now
-  double ring[8][4];
-  bk_finish_load<15>(ring[7], Lg, N, q, j); bk_finish_load<14>(ring[6], Lg, N, q, j);
-  bk_finish_load<13>(ring[5], Lg, N, q, j); bk_finish_load<12>(ring[4], Lg, N, q, j);
-  bk_finish_load<11>(ring[3], Lg, N, q, j); bk_finish_load<10>(ring[2], Lg, N, q, j);
-  bk_finish_load<9>(ring[1], Lg, N, q, j); bk_finish_load<8>(ring[0], Lg, N, q, j);
-  double wl[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wl[i] = Wg[tid + 1024 * i];
   if (tid < BK_N1) a2s[tid] = tid < n2 ? al[BK_N1 + tid] : 0.0;
   __syncthreads();
   {
     // w = L21^T alpha2: thread (q, j) sums its quarter of the rows of column j (rows read coalesced, 16 in flight)
-    const int r0 = q * 64;
-    const double* col = Lg + (size_t)(BK_N1 + r0) * N + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll 1
     for (int rb = 0; rb < 64; rb += 16) {
       if (r0 + rb >= n2) break;
-      double cv[16];
+      if (rb > 0) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) cv[k] = r0 + rb + k < n2 ? col[(size_t)(rb + k) * N] : 0.0;
+        for (int k = 0; k < 16; ++k) cv[k] = r0 + rb + k < N2 ? col[(size_t)(rb + k) * N] : 0.0;
+      }
 #pragma unroll
       for (int k = 0; k < 16; k += 4) {
         s0 = __builtin_fma(cv[k], a2s[r0 + rb + k], s0);
@@ -523,6 +527,9 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
     }
     part[q][j] = (s0 + s1) + (s2 + s3);
   }
+  // (block rows 11 .. 8 are needed four steps from now)
+  bk_finish_load<11>(ring[3], Lg, N, q, j); bk_finish_load<10>(ring[2], Lg, N, q, j);
+  bk_finish_load<9>(ring[1], Lg, N, q, j); bk_finish_load<8>(ring[0], Lg, N, q, j);
 #pragma unroll
   for (int i = 0; i < 4; ++i) Wl[tid + 1024 * i] = wl[i];
   __syncthreads();
