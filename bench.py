@@ -9,15 +9,20 @@ L-BFGS evaluation of the meta-fit (the reference's HOT LOOP #2, scamlgp/utils.py
 
 Multi-GPU (BASELINE.json configs[3]: task shards + "RCCL all-reduce of the MLL hyper-gradient"):
 ``python bench.py --gpus N`` starts N fresh child ranks itself (torch.distributed.run, one rank per
-GPU over RCCL); the driver may also launch the ranks directly.  Every rank owns its own 256-task
-shard (weak scaling; 1024 tasks = 4 GPUs' worth).  The shards' only coupling is a sum over tasks
-(scamlgp/model.py:129-134): ONE all-reduce per timed region carries the fused buffer
+GPU over RCCL); the driver may also launch the ranks directly.  Default: every rank owns its own
+256-task shard (weak scaling).  ``--total-tasks 1024`` is configs[3] as BASELINE.json states it: 1024
+tasks in all, ``dist.shard_range(1024, N, rank)`` of them per rank (strong scaling; 128 per GPU at N = 8).
+The shards' only coupling is a sum over tasks (scamlgp/model.py:129-134): ONE all-reduce per timed
+region carries the fused buffer
     [ sum_t MLL_t of every step of the region  ||  sum_t dMLL_t/dtheta (D + 2) ]
-where the gradient sum comes from one fit + backward evaluation over the shard that closes the region
-(with ``--step fit+grad``: from every step).  The collective is batched on purpose: a collective per
-step would put an RCCL workgroup on one of the 256 CUs the next launch's one-per-CU workgroups need.
-The same region (steps + closing backward + reduce) is timed at every N, N = 1 included, so the
-per-N values are comparable.
+The timed region is EXACTLY the K steps + that one reduce; nothing else is enqueued inside it.  With
+``--step fit`` the gradient slot of the buffer is filled by one fit + backward evaluation BEFORE the
+region (it is not part of the metric's step); with ``--step fit+grad`` every step adds its gradient.
+The collective is batched on purpose: a collective per step would put an RCCL workgroup on one of the
+256 CUs the next launch's one-per-CU workgroups need.
+Clock ramp: a fresh process finds the GPU at idle clocks, and 25 launches do not bring it to its
+steady state; a FIXED, untimed prologue of ``--prewarm`` launches of the same kernel (default 2000,
+~0.2 s; reported as ``prewarm_launches``) runs before the ``--warmup`` steps at every N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     — algorithmic fp64 flops per launch / measured kernel duration vs the fp64 MFMA peak
@@ -74,18 +79,18 @@ def recorded_pmc_traffic():
         return None
 
 
-def make_inputs(rank: int, device):
+def make_inputs(rank: int, device, T: int = T_PER_GPU):
     import numpy as np
     import torch
     from scamlgp_amd import synthetic
 
-    d = synthetic.smooth_field_task_stack(T_PER_GPU, N_POINTS, DIM, seed=1234 + rank)
+    d = synthetic.smooth_field_task_stack(T, N_POINTS, DIM, seed=1234 + rank)
     ys, _, _ = synthetic.standardize_rows(d["Y"])
     rng = np.random.default_rng(4321 + rank)
     # reference inits (scamlgp/model.py:55, 67, 31): lengthscale 0.5 (ARD, +-20 % per dim so the
     # ARD path is exercised), outputscale 1.0, noise 1e-3
     theta = np.concatenate(
-        [0.5 * (1 + 0.4 * (rng.uniform(size=(T_PER_GPU, DIM)) - 0.5)), np.full((T_PER_GPU, 1), 1.0), np.full((T_PER_GPU, 1), 1e-3)], 1)
+        [0.5 * (1 + 0.4 * (rng.uniform(size=(T, DIM)) - 0.5)), np.full((T, 1), 1.0), np.full((T, 1), 1e-3)], 1)
     X = torch.from_numpy(d["X"])
     y = torch.from_numpy(ys)
     th = torch.from_numpy(theta)
@@ -128,6 +133,7 @@ def cpu_baseline(host_inputs, budget_s: float = 4.0):
     from oracle import gp_oracle as O
 
     X, y, th = host_inputs
+    T_PER_GPU = int(X.shape[0])   # (the sample cycles through the rank's own stack)
     cores = os.cpu_count() or torch.get_num_threads()
     all_threads = torch.get_num_threads()
     O.gp_fit_stack_loop(X[:2], y[:2], th[:2], O.KIND_MATERN52)  # warm-up
@@ -198,25 +204,37 @@ def _free_port() -> int:
     return p
 
 
+def _visible_gpus(env):
+    """Number of GPUs a rank will see, asked of a child process that exits at once (None if it cannot tell)."""
+    try:
+        res = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True, timeout=600)
+        return int(res.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: build once, then start N fresh child ranks
     (no GPU call has happened in this process) and relay their output and exit code."""
     import __graft_entry__ as entry
 
-    entry.build()   # once, here: the ranks then find an up-to-date library and do not race writing it
-    import torch
-
-    have = torch.cuda.device_count()   # (does not initialise the GPU)
+    # once, here: the ranks then find an up-to-date library and do not race writing it.  This process neither imports torch nor
+    # loads the library nor makes a HIP call: a launcher that has opened the GPU must not be the parent of the ranks.
+    entry.build(import_package=False)
     env = dict(os.environ)
-    if have < args.gpus and env.get("SCAML_BENCH_REHEARSAL") != "1":
-        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {have} visible "
-                         "(SCAML_BENCH_REHEARSAL=1 rehearses the multi-rank control flow on one GPU; its numbers mean nothing)\n")
-        return 2
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("SCAML_BENCH_REHEARSAL") != "1":
+        have = _visible_gpus(env)   # counted by a throwaway child
+        if have is not None and have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs, {have} visible "
+                             "(SCAML_BENCH_REHEARSAL=1 rehearses the multi-rank control flow on one GPU; its numbers mean nothing)\n")
+            return 2
     env["SCAML_BENCH_PARENT_BUILT"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__),
-           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--step", args.step]
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--step", args.step,
+           "--prewarm", str(args.prewarm), "--total-tasks", str(args.total_tasks)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -240,6 +258,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--step", choices=("fit", "fit+grad"), default="fit",
                     help="fit: the metric's step (K + Cholesky + solves + MLL); fit+grad: + the hyper-gradient every step")
+    ap.add_argument("--prewarm", type=int, default=2000,
+                    help="fixed untimed prologue: launches of the step's kernel before --warmup, to bring a fresh GPU to steady clocks")
+    ap.add_argument("--total-tasks", type=int, default=0,
+                    help="strong scaling: this many tasks IN ALL, sharded over the ranks (1024 = BASELINE configs[3]); "
+                         "0 = weak scaling, 256 tasks per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -259,6 +282,9 @@ def main():
     # RCCL, which refuses two ranks on one device).  Numbers from such a run mean nothing; it exists so that the
     # barrier / all-reduce / max-over-ranks logic can be exercised on a one-GPU box.
     rehearsal = os.environ.get("SCAML_BENCH_REHEARSAL") == "1"
+    if not rehearsal and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible "
+                         "(SCAML_BENCH_REHEARSAL=1 rehearses the multi-rank control flow on one GPU; its numbers mean nothing)")
     device = torch.device("cuda", 0 if rehearsal else local_rank)
     distributed = world > 1
     if distributed:
@@ -272,19 +298,30 @@ def main():
     entry.build()
     torch.cuda.set_device(device)
     from scamlgp_amd import ops
+    from scamlgp_amd.dist import shard_range
 
-    host_inputs, (X, y, th) = make_inputs(rank, device)
+    strong = args.total_tasks > 0
+    if strong:
+        lo, hi = shard_range(args.total_tasks, world, rank)
+        T_loc = hi - lo
+        if T_loc < 1:
+            raise SystemExit(f"--total-tasks {args.total_tasks} leaves rank {rank} of {world} without a task")
+        total_tasks = args.total_tasks
+    else:
+        T_loc, total_tasks = T_PER_GPU, world * T_PER_GPU
+    host_inputs, (X, y, th) = make_inputs(rank, device, T_loc)
     kind = ops.KIND_MATERN52
     with_grad = args.step == "fit+grad"
     # allocates the output buffers once; every step rewrites them completely
     out = ops.gp_fit_fused(X, y, th, kind)
     out_g = ops.gp_fit_fused(X, y, th, kind, want_linv=True)   # the evaluation with a gradient also keeps the diagonal-block inverses
-    gws = ops.mll_backward_workspace(T_PER_GPU, N_POINTS, DIM, device)
-    total = args.warmup + args.steps
-    # Every step writes its per-task MLLs into its own row; the region's ONE all-reduce carries
-    # [sum_t MLL_t per step || sum_t dMLL_t/dtheta] (one fused buffer, several evaluations per collective).
-    mll_rows = torch.zeros(total, T_PER_GPU, dtype=torch.float64, device=device)
-    grad_acc = torch.zeros(DIM + 2, dtype=torch.float64, device=device)
+    gws = ops.mll_backward_workspace(T_loc, N_POINTS, DIM, device)
+    rows = max(args.warmup, args.steps, 1)
+    # Every step writes its per-task MLLs into its own row; the region's ONE all-reduce carries the fused buffer
+    # [sum_t MLL_t per step || sum_t dMLL_t/dtheta] (one buffer, several evaluations per collective).
+    mll_rows = torch.zeros(rows, T_loc, dtype=torch.float64, device=device)
+    fused = torch.zeros(rows + DIM + 2, dtype=torch.float64, device=device)
+    grad_acc = fused[rows:]
     works = []
 
     def step(i):
@@ -294,19 +331,15 @@ def main():
         if with_grad:
             grad_acc.add_(ops.mll_backward(X, th, kind, o["L"], o["Linv_diag"], o["alpha"], workspace=gws).sum(0))
 
-    def close_region(lo, hi):
-        """The evaluation that ends a region: hyper-gradient of the last step's factors (unless every step had one),
-        then the fused buffer goes through the one collective."""
-        if not with_grad:
-            ops.gp_fit_fused(X, y, th, kind, out=out_g, zero_upper=True, want_linv=True)
-            grad_acc.copy_(ops.mll_backward(X, th, kind, out_g["L"], out_g["Linv_diag"], out_g["alpha"], workspace=gws).sum(0))
-        buf = torch.cat([mll_rows[lo:hi].sum(1), grad_acc])
+    def reduce_region(k):
+        """The region's exchange step: the per-step MLL sums go next to the gradient sums, the fused buffer goes through
+        the one collective."""
+        torch.sum(mll_rows[:k], 1, out=fused[:k])
         if distributed:
-            works.append((dist.all_reduce(buf, async_op=True), buf))
-        return buf
+            works.append(dist.all_reduce(fused, async_op=True))
 
     def fence():
-        for w, _ in works:
+        for w in works:
             w.wait()
         works.clear()
         torch.cuda.synchronize()
@@ -314,10 +347,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def grad_outside_region():
+        # --step fit: the hyper-gradient slot of the buffer comes from ONE evaluation outside the timed region
+        ops.gp_fit_fused(X, y, th, kind, out=out_g, zero_upper=True, want_linv=True)
+        grad_acc.copy_(ops.mll_backward(X, th, kind, out_g["L"], out_g["Linv_diag"], out_g["alpha"], workspace=gws).sum(0))
+
+    # Untimed prologue, the same at every N and for every --steps / --warmup.  (1) Every code path of the run once: the first
+    # launch of a kernel, the first collective, the first event cost the host tens of milliseconds of lazy set-up during which
+    # the GPU idles -- and an MI355X that has idled for ~20 ms drops its clocks and needs ~10 ms (60+ launches) of load to get
+    # them back (tools/dev_launch_ramp.py: 117 instead of 107 us per launch).  (2) --prewarm launches of the step's kernel.
+    # From here to the timed region the GPU never idles for more than a synchronisation.
+    step(0)
+    grad_outside_region()
+    reduce_region(1)
+    fence()
+    torch.cuda.Event(enable_timing=True).record()
+    for _ in range(args.prewarm):
+        ops.gp_fit_fused(X, y, th, kind, out=out, zero_upper=True)
     for i in range(args.warmup):
         step(i)
-    close_region(0, args.warmup)
+    reduce_region(args.warmup)
+    fence()
     grad_acc.zero_()
+    if not with_grad:
+        grad_outside_region()
     fence()
     # the dominant kernel's launches are timed with HIP events on the stream they are launched on (torch's current
     # stream: ops passes torch.cuda.current_stream() across the C ABI)
@@ -326,9 +379,9 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(i)
     ev1.record()
-    reduced = close_region(args.warmup, total)   # inside the timed region
+    reduce_region(args.steps)   # inside the timed region: one small sum + the one all-reduce
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # launch stream only: avg duration of one step's launches
@@ -338,46 +391,50 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     ok = not bool(out["info"].any().item())
-    reduced = reduced.cpu()
+    reduced = fused.cpu()
 
     if rank == 0:
-        flops = algorithmic_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
+        flops = algorithmic_flops_per_task(N_POINTS, DIM, True) * T_loc
         if with_grad:
-            flops += algorithmic_backward_flops_per_task(N_POINTS, DIM, True) * T_PER_GPU
+            flops += algorithmic_backward_flops_per_task(N_POINTS, DIM, True) * T_loc
         achieved = flops / (kernel_ms * 1e-3) / 1e12
         res = {
             "metric": "task-posteriors/sec (K+chol+solve+MLL) at T=256,N=256; 1/2/4/8 GPU",
-            "value": world * T_PER_GPU * args.steps / elapsed,
+            "value": total_tasks * args.steps / elapsed,
             "unit": "task-posteriors/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_launches": args.prewarm,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[2]: 256 meta-tasks x 256 points x d=8, Matern-5/2 + ARD, per GPU "
-                            "(fused K + jittered Cholesky + alpha + MLL, L stored)"
+                "workload": (f"configs[3]: {total_tasks} meta-tasks x 256 points x d=8, Matern-5/2 + ARD, task-sharded over {world} GPU(s) "
+                             f"({T_loc} tasks on rank 0)" if strong else
+                             "configs[2]: 256 meta-tasks x 256 points x d=8, Matern-5/2 + ARD, per GPU")
+                            + " (fused K + jittered Cholesky + alpha + MLL, L stored)"
                             + (" + analytic MLL hyper-gradient every step" if with_grad else ""),
                 "step": args.step,
-                "tasks_per_gpu": T_PER_GPU, "points": N_POINTS, "dim": DIM, "kernel": "matern52",
-                "sharding": ("task shards (configs[3] layout: 1024 tasks = 4 such shards), " if distributed else "single GPU, ")
-                            + "one fused all-reduce [sum MLL per step || sum dMLL/dtheta] per timed region"
+                "tasks_per_gpu": T_loc, "total_tasks": total_tasks, "points": N_POINTS, "dim": DIM, "kernel": "matern52",
+                "sharding": ("task shards, " if distributed else "single GPU, ")
+                            + "timed region = the steps + one fused all-reduce [sum MLL per step || sum dMLL/dtheta]"
                             + (" (REHEARSAL: all ranks on one GPU over gloo, numbers meaningless)" if rehearsal and distributed else ""),
                 "all_tasks_psd": ok,
                 "reduced_mll_sum_last_step": float(reduced[args.steps - 1]),
-                "reduced_grad_norm": float(reduced[args.steps:].norm()),
+                "reduced_grad_norm": float(reduced[rows:].norm()),
             },
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP64_TFLOPS, "traffic": recorded_pmc_traffic() if not with_grad else None,
-                "kernel": "gp_fit_fused_kernel<16,7,matern52>" + (" + gp_linv_kernel + gp_mll_grad_kernel" if with_grad else ""),
+                "frac": achieved / PEAK_FP64_TFLOPS,
+                "traffic": recorded_pmc_traffic() if (not with_grad and T_loc == T_PER_GPU) else None,
+                "kernel": "gp_fit_fused_kernel<16,7,matern52>" + (" + gp_mll_grad_fused_kernel" if with_grad else ""),
                 "kernel_ms": kernel_ms,
                 "algorithmic_flops_per_launch": flops,
-                "algorithmic_bytes_per_launch": algorithmic_bytes_per_task(N_POINTS, DIM) * T_PER_GPU,
+                "algorithmic_bytes_per_launch": algorithmic_bytes_per_task(N_POINTS, DIM) * T_loc,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

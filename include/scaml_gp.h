@@ -247,6 +247,45 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
                             double m_all, double s_all, double noise_add, const int32_t* info, int n, int M, double* mu, double* var,
                             void* stream);
 
+/*
+ * (8) The target GP's training objective with its analytic gradient, and the whole refit, in ONE launch.
+ * Replaces what the reference runs on every report(): scamlgp/optimizer.py:176-185 rebuilds ScaMLGP and calls
+ * optimize_marginal_likelihood (scamlgp/utils.py:139-212), which drives scipy L-BFGS-B through torch autograd over
+ *   mll(z) = [ log N(y~ | mean, cov + noise I) + sum log priors ] / n                       (scamlgp/model.py:360-363, 376-383)
+ *   mean = (source_means w - m_all) / s_all,   cov = source_covs w^2 / s_all^2 + os k_t(X, X; l)
+ * with the source terms cached at construction (scamlgp/model.py:279-289) and the priors / constraints of
+ * scamlgp/model.py:25-33, 73-105, 318-338.
+ *   z (B, P), P = D + 2 + T: B independent parameter vectors [raw lengthscales (D), raw outputscale, raw noise, weights (T)] --
+ *       the warm start and the prior-sampled restarts of utils.py:184-199 side by side; raw = unconstrained values of the
+ *       sigmoid Interval constraints, weights as they are (GreaterThan(1e-10, transform=None): a box bound for the optimiser).
+ *   means_t (T, n): source posterior means at the target inputs (source_means transposed), original units.
+ *   covs_packed (T, n (n + 1) / 2): source posterior covariances, lower triangle packed row-wise -- element (a, b), a >= b, at
+ *       a (a + 1) / 2 + b (source_covs[a, b, t]).
+ *   X (n, D), y (n): target inputs and observations standardised with (m_all, s_all) (scamlgp/model.py:264-276, 309-316).
+ *   spec_host: HOST pointer to 19 doubles (read during the call; the one exception to "every pointer is a device pointer"):
+ *       [ls_lo, ls_hi, os_lo, os_hi, noise_lo, noise_hi,  then (kind, p1, p2) for the lengthscale, outputscale, noise and
+ *       weight priors -- kind 0 none, 1 Gamma(concentration p1, rate p2), 2 LogNormal(loc p1, scale p2) --,  w_lower].
+ * scaml_target_mll_f64: value (B) = mll(z_b), grad (B, P) = d mll / d z_b, info (B) (k > 0: pivot k not positive even with
+ *   jitter 1e-6 -- psd_safe_cholesky's ladder runs in-kernel --, value = NaN then), jitter_used (B, may be NULL).
+ * scaml_target_fit_f64: maximises mll from every row of z (in: start points, out: optima) with an L-BFGS (history pairs,
+ *   projected backtracking line search on w >= w_lower, scipy L-BFGS-B's stopping rules: projected gradient <= gtol, relative
+ *   decrease <= ftol, max_iter iterations), entirely on the device; value (B) = mll at the returned point, stats (B, 4)
+ *   (may be NULL) = [iterations, evaluations, status, 0], status 1 / 2 converged (gradient / decrease), 0 max_iter,
+ *   3 line search failed, 4 objective not finite at the start point.  workspace: scaml_target_fit_workspace_doubles(...) doubles.
+ * One workgroup per row of z, the n x n matrix in LDS: n <= scaml_target_fit_max_n(T, D) (128 at T = 32, D = 6),
+ * D <= scaml_target_fit_max_d(); SCAML_E_TOOLARGE otherwise.
+ */
+int scaml_target_fit_max_n(int T, int D);
+int scaml_target_fit_max_d(void);
+long long scaml_target_fit_workspace_doubles(int B, int T, int D, int history);
+int scaml_target_mll_f64(const double* means_t, const double* covs_packed, const double* X, const double* y, double m_all, double s_all,
+                         const double* spec_host, const double* z, int B, int n, int T, int D, int kind, double* value, double* grad,
+                         int32_t* info, double* jitter_used, void* stream);
+int scaml_target_fit_f64(const double* means_t, const double* covs_packed, const double* X, const double* y, double m_all, double s_all,
+                         const double* spec_host, double* z, int B, int n, int T, int D, int kind, int max_iter, int history, double gtol,
+                         double ftol, double* value, int32_t* info, double* jitter_used, int32_t* stats, double* workspace,
+                         long long workspace_doubles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

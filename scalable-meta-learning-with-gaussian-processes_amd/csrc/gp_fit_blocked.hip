@@ -433,7 +433,8 @@ __global__ __launch_bounds__(512, 4) void gp_blocked_syrk_kernel(BlockedFitParam
 // that 16-step chain waits for global memory: all W_kb sit in LDS, thread (q, j) holds rows 4 q .. 4 q + 3 of the block
 // rows in a ring of registers filled eight steps ahead, every wave forms u_kb for itself (no hand-over through LDS), and
 // the partial sums of the four quarters meet in LDS atomics: one barrier per step.  (A ragged block 1 rides on the identity
-// padding of W_kb and on the zero rows of L the caller provides, include/scaml_gp.h.)
+// padding of W_kb; rows of L at or past n1 are never written by the fit -- include/scaml_gp.h -- and may hold anything, NaN bit
+// patterns included: the ring is loaded before n1 is known, so the step masks those rows where it uses them.)
 template <int KB>
 __device__ __forceinline__ void bk_finish_load(double (&dst)[4], const double* Lg, int N, int q, int j) {
 #pragma unroll
@@ -442,7 +443,7 @@ __device__ __forceinline__ void bk_finish_load(double (&dst)[4], const double* L
 
 template <int KB>
 __device__ __forceinline__ void bk_finish_step(const double (&lrow)[4], const double* Wl, const double* w, double (*pw)[BK_N1], double* u, double& mine,
-                                               int q, int j, int lane) {
+                                               int q, int j, int lane, int n1) {
   __syncthreads();   // the four quarters' running sums for block KB are in pw
   // u_kb[c] on lane (c = lane % 16, any lane / 16): every wave computes all of it
   const int c = lane & 15, rg = lane >> 4;
@@ -458,7 +459,7 @@ __device__ __forceinline__ void bk_finish_step(const double (&lrow)[4], const do
   if constexpr (KB > 0) {
     // thread (q, j) keeps ITS share of sum_r L[r][j] u[r] over all steps in a register and hands it over when column j's block is next
 #pragma unroll
-    for (int i = 0; i < 4; ++i) mine = __builtin_fma(lrow[i], readlane_f64(xv, 4 * q + i), mine);
+    for (int i = 0; i < 4; ++i) mine = __builtin_fma(16 * KB + 4 * q + i < n1 ? lrow[i] : 0.0, readlane_f64(xv, 4 * q + i), mine);
     if (j >= 16 * (KB - 1) && j < 16 * KB) pw[q][j] = mine;
   }
 }
@@ -537,18 +538,18 @@ extern "C" __global__ __launch_bounds__(1024) void scaml_blocked_finish_kernel(B
   pw[q][j] = 0.0;
   double mine = 0.0;
   BK_STAMP(100);   // mat-vec done
-  bk_finish_step<15>(ring[7], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<7>(ring[7], Lg, N, q, j);
-  bk_finish_step<14>(ring[6], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<6>(ring[6], Lg, N, q, j);
-  bk_finish_step<13>(ring[5], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<5>(ring[5], Lg, N, q, j);
-  bk_finish_step<12>(ring[4], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<4>(ring[4], Lg, N, q, j);
-  bk_finish_step<11>(ring[3], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<3>(ring[3], Lg, N, q, j);
-  bk_finish_step<10>(ring[2], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<2>(ring[2], Lg, N, q, j);
-  bk_finish_step<9>(ring[1], Wl, w, pw, u, mine, q, j, lane); bk_finish_load<1>(ring[1], Lg, N, q, j);
-  bk_finish_step<8>(ring[0], Wl, w, pw, u, mine, q, j, lane);
-  bk_finish_step<7>(ring[7], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<6>(ring[6], Wl, w, pw, u, mine, q, j, lane);
-  bk_finish_step<5>(ring[5], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<4>(ring[4], Wl, w, pw, u, mine, q, j, lane);
-  bk_finish_step<3>(ring[3], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<2>(ring[2], Wl, w, pw, u, mine, q, j, lane);
-  bk_finish_step<1>(ring[1], Wl, w, pw, u, mine, q, j, lane); bk_finish_step<0>(ring[0], Wl, w, pw, u, mine, q, j, lane);
+  bk_finish_step<15>(ring[7], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<7>(ring[7], Lg, N, q, j);
+  bk_finish_step<14>(ring[6], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<6>(ring[6], Lg, N, q, j);
+  bk_finish_step<13>(ring[5], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<5>(ring[5], Lg, N, q, j);
+  bk_finish_step<12>(ring[4], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<4>(ring[4], Lg, N, q, j);
+  bk_finish_step<11>(ring[3], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<3>(ring[3], Lg, N, q, j);
+  bk_finish_step<10>(ring[2], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<2>(ring[2], Lg, N, q, j);
+  bk_finish_step<9>(ring[1], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_load<1>(ring[1], Lg, N, q, j);
+  bk_finish_step<8>(ring[0], Wl, w, pw, u, mine, q, j, lane, n1);
+  bk_finish_step<7>(ring[7], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_step<6>(ring[6], Wl, w, pw, u, mine, q, j, lane, n1);
+  bk_finish_step<5>(ring[5], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_step<4>(ring[4], Wl, w, pw, u, mine, q, j, lane, n1);
+  bk_finish_step<3>(ring[3], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_step<2>(ring[2], Wl, w, pw, u, mine, q, j, lane, n1);
+  bk_finish_step<1>(ring[1], Wl, w, pw, u, mine, q, j, lane, n1); bk_finish_step<0>(ring[0], Wl, w, pw, u, mine, q, j, lane, n1);
   __syncthreads();
   BK_STAMP(101);   // chain done
   if (tid < n1) al[tid] = u[tid];

@@ -1,0 +1,549 @@
+// gp_target_fit.hip — the target GP's training objective, its analytic gradient and the whole L-BFGS refit in ONE launch.
+//
+// Replaces what the reference runs on every report(): scamlgp/optimizer.py:176-185 rebuilds ScaMLGP and calls
+// optimize_marginal_likelihood (scamlgp/utils.py:139-212), which drives scipy L-BFGS-B over
+//   mll(z) = [ log N(y~ | mean, cov + sigma^2 I) + log priors ] / n                 (scamlgp/model.py:360-363, 376-383)
+//   mean = (source_means w - m_all) / s_all,  cov = source_covs w^2 / s_all^2 + os k_t(X, X; l)
+// with torch autograd through kernel, Cholesky and solves per evaluation -- ~700 evaluations per BO step at BASELINE configs[4].
+// Here one workgroup owns one start point (the warm start and every prior-sampled restart run side by side): the n x n matrix
+// lives in LDS, an evaluation is
+//   build      cov from the packed source covariances (coalesced over elements, sum over tasks), target kernel, noise, jitter
+//   eliminate  square-root-free Cholesky (A = L~ D^-1 L~^T, same pivots as LL^T) by columns; the right-hand side rides along as
+//              row n (its Schur complement is -quad) and the identity as n more right-hand sides, so ONE sweep with ONE barrier
+//              per column yields pivots, L^-1 y and L^-1 -- no separate triangular solves
+//   K^-1, alpha, G = (alpha alpha^T - K^-1) / 2 in place
+//   gradient   d/dw_i = <G, 2 w_i C_i / s^2> + alpha . M_i / s   (one wave per task, coalesced over the packed elements)
+//              d/d(l, os, noise) from one pass over the kernel elements; chain rule through the sigmoid Interval, priors
+// and the optimiser (two-loop L-BFGS, projected backtracking line search on the box w >= w_lower, scipy L-BFGS-B's stopping
+// rules) runs in the same kernel on vectors in a small global workspace.  psd_safe_cholesky's jitter ladder (0, 1e-8, 1e-7,
+// 1e-6 on the diagonal) is applied per evaluation, in-kernel.
+//
+// Layout: packed lower triangle everywhere -- element (a, b), a >= b, at a (a + 1) / 2 + b.  Throughput is not the point of
+// this kernel (B <= a handful of workgroups on an otherwise idle chip); latency per evaluation is: plain fp64 VALU + LDS, no
+// matrix-core tiles (n <= 128, a 16-column panel would leave the serial pivot chain as it is).
+//
+// SCAML_HOST_EMUL: the same source compiles as single-threaded host code (tests/host_emul: arithmetic of objective, gradient
+// and optimiser checked against the oracle on CPU; never part of libscaml_hip.so).
+#ifndef SCAML_HOST_EMUL
+#include <hip/hip_runtime.h>
+#include "scaml_common.hpp"
+#define TF_DEV __device__ __forceinline__
+#define TF_DEV_CALL __device__ __noinline__   // one copy of the evaluation: the optimiser calls it from three places
+#define TF_SYNC() __syncthreads()
+#define TF_LANES 64
+#else
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#define TF_DEV static inline
+#define TF_DEV_CALL static
+#define TF_SYNC() ((void)0)
+#define TF_LANES 1
+#endif
+#include "gp_target_params.h"
+
+namespace scaml {
+
+struct TfCtx {
+  int tid, nthr, lane, wave, nwave;
+  int n, T, D, P, E, kind;
+  // LDS
+  double *Ap, *Tp, *Xs, *col, *piv, *rs, *alpha, *vv, *w, *w2, *theta, *dth, *invl, *part, *red, *sc;
+};
+
+TF_DEV int tf_idxL(int a, int b) { return a * (a + 1) / 2 + b; }
+TF_DEV int tf_rowT(int j, int n) { return j * n - j * (j - 1) / 2 - j; }   // row j of the upper-packed block: (j, k), k >= j, at tf_rowT(j) + k
+TF_DEV int tf_idxT(int j, int k, int n) { return tf_rowT(j, n) + k; }
+
+TF_DEV void tf_decode(int e, int& a, int& b) {
+  int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+  while (r * (r + 1) / 2 > e) --r;
+  while ((r + 1) * (r + 2) / 2 <= e) ++r;
+  a = r;
+  b = e - r * (r + 1) / 2;
+}
+
+// total over the wave, valid in the last lane
+TF_DEV double tf_wave_sum(double x) {
+#ifndef SCAML_HOST_EMUL
+  return wave_sum_to_lane15(x);
+#else
+  return x;
+#endif
+}
+TF_DEV bool tf_last_lane(const TfCtx& c) { return c.lane == TF_LANES - 1; }
+
+// sum over the workgroup, result in every thread (fixed order: deterministic).  Two barriers.
+TF_DEV double tf_block_sum(const TfCtx& c, double x) {
+  const double s = tf_wave_sum(x);
+  if (tf_last_lane(c)) c.red[c.wave] = s;
+  TF_SYNC();
+  double t = 0.0;
+  for (int v = 0; v < c.nwave; ++v) t += c.red[v];
+  TF_SYNC();
+  return t;
+}
+TF_DEV double tf_block_max(const TfCtx& c, double x) {
+  // (max needs no order; reuse the sum path: waves publish their lanes' maxima through LDS)
+#ifndef SCAML_HOST_EMUL
+  for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+#endif
+  if (c.lane == 0) c.red[c.wave] = x;
+  TF_SYNC();
+  double t = c.red[0];
+  for (int v = 1; v < c.nwave; ++v) t = fmax(t, c.red[v]);
+  TF_SYNC();
+  return t;
+}
+
+TF_DEV double tf_prior_logp(const TargetPrior& p, double x) {
+  if (p.kind == 1) return p.c0 + (p.p1 - 1.0) * log(x) - p.p2 * x;
+  if (p.kind == 2) {
+    const double lx = log(x), u = (lx - p.p1) / p.p2;
+    return p.c0 - lx - 0.5 * u * u;
+  }
+  return 0.0;
+}
+TF_DEV double tf_prior_dlogp(const TargetPrior& p, double x) {
+  if (p.kind == 1) return (p.p1 - 1.0) / x - p.p2;
+  if (p.kind == 2) return -(1.0 + (log(x) - p.p1) / (p.p2 * p.p2)) / x;
+  return 0.0;
+}
+
+// k(x_a, x_b) / os and d(k / os) / d(d2) for the scaled squared distance d2 (a != b)
+TF_DEV void tf_kernel(int kind, double d2, double& kk, double& dk) {
+  if (kind == 0) {
+    kk = exp(-0.5 * d2);
+    dk = -0.5 * kk;
+  } else {
+    const double s5 = 2.2360679774997896964;
+    const double r = sqrt(fmax(d2, 1e-30));   // gpytorch clamps the squared distance before the root
+    const double e5 = exp(-s5 * r);
+    kk = (1.0 + s5 * r + (5.0 / 3.0) * r * r) * e5;
+    dk = -(5.0 / 6.0) * (1.0 + s5 * r) * e5;
+  }
+}
+
+// One evaluation at z (P doubles, global): returns mll (every thread) and, if gz != nullptr, d mll / d z.
+// info_out / jit_out: status of the factorisation (thread 0 writes them if given).  A matrix that is not positive definite
+// even with the largest jitter gives NaN.
+TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z, double* gz, int32_t* info_out, double* jit_out) {
+  const int n = c.n, T = c.T, D = c.D, E = c.E;
+  const TargetSpec& sp = p.spec;
+  const double inv_s = 1.0 / p.s_all, inv_s2 = inv_s * inv_s;
+  // ---- parameters ----
+  for (int i = c.tid; i < D + 2; i += c.nthr) {
+    const double lo = i < D ? sp.ls_lo : (i == D ? sp.os_lo : sp.nz_lo), hi = i < D ? sp.ls_hi : (i == D ? sp.os_hi : sp.nz_hi);
+    const double s = 1.0 / (1.0 + exp(-z[i]));
+    const double th = lo + (hi - lo) * s;
+    c.theta[i] = th;
+    c.dth[i] = (hi - lo) * s * (1.0 - s);
+    if (i < D) c.invl[i] = 1.0 / th;
+  }
+  for (int i = c.tid; i < T; i += c.nthr) {
+    const double wi = z[D + 2 + i];
+    c.w[i] = wi;
+    c.w2[i] = wi * wi * inv_s2;
+  }
+  TF_SYNC();
+  const double os = c.theta[D], noise = c.theta[D + 1];
+  int fail = 0;
+  double jit = 0.0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    jit = attempt == 0 ? 0.0 : (attempt == 1 ? 1e-8 : (attempt == 2 ? 1e-7 : 1e-6));
+    // ---- build ----
+    for (int e = c.tid; e < E; e += c.nthr) {
+      int a, b;
+      tf_decode(e, a, b);
+      double acc = 0.0;
+      const double* cp = p.covs_p + e;
+      for (int i = 0; i < T; ++i) acc += c.w2[i] * cp[(size_t)i * E];
+      double k = os;
+      if (a != b) {
+        double d2 = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double df = (c.Xs[a * D + d] - c.Xs[b * D + d]) * c.invl[d];
+          d2 += df * df;
+        }
+        double kk, dk;
+        tf_kernel(c.kind, d2, kk, dk);
+        k = os * kk;
+      } else {
+        k += noise + jit;
+      }
+      c.Ap[e] = acc + k;
+      c.Tp[e] = 0.0;
+    }
+    for (int b = c.tid; b < n; b += c.nthr) {
+      double m = 0.0;
+      for (int i = 0; i < T; ++i) m += c.w[i] * p.means_t[(size_t)i * n + b];
+      c.Ap[tf_idxL(n, b)] = p.y[b] - (m - p.m_all) * inv_s;
+    }
+    if (c.tid == 0) c.Ap[tf_idxL(n, n)] = 0.0;
+    TF_SYNC();
+    for (int j = c.tid; j < n; j += c.nthr) c.Tp[tf_idxT(j, j, n)] = 1.0;
+    for (int b = c.tid; b <= n; b += c.nthr) c.col[b] = c.Ap[tf_idxL(b, 0)];
+    TF_SYNC();
+    // ---- elimination: column k of the (n + 1) x (n + 1) bordered matrix, rows of the identity block riding along ----
+    fail = 0;
+    for (int k = 0; k < n; ++k) {
+      const double* cur = c.col + (k & 1) * (n + 1);
+      double* nxt = c.col + ((k + 1) & 1) * (n + 1);
+      const double pv = cur[k];
+      if (!(pv > 0.0)) {   // (uniform: every thread reads the same LDS word; NaN lands here too)
+        fail = k + 1;
+        break;
+      }
+      const double inv = 1.0 / pv;
+      for (int r = c.wave; r <= n; r += c.nwave) {
+        if (r <= k) {      // identity block: row r holds (L~^-1)^T e_r so far, columns k + 1 .. n - 1 still to go
+          const int base = tf_rowT(r, n);
+          const double f = c.Tp[base + k] * inv;
+          if (f != 0.0) {
+            for (int b = k + 1 + c.lane; b < n; b += TF_LANES) c.Tp[base + b] -= f * cur[b];
+          }
+        } else {           // matrix rows (r == n: the right-hand side, whose diagonal entry collects -quad)
+          const int base = tf_idxL(r, 0);
+          const double f = cur[r] * inv;
+          for (int b = k + 1 + c.lane; b <= r; b += TF_LANES) {
+            const double v = c.Ap[base + b] - f * cur[b];
+            c.Ap[base + b] = v;
+            if (b == k + 1) nxt[r] = v;
+          }
+        }
+      }
+      TF_SYNC();
+    }
+    if (!fail) break;
+    TF_SYNC();
+  }
+  if (info_out && c.tid == 0) *info_out = fail;
+  if (jit_out && c.tid == 0) *jit_out = jit;
+  if (fail) {
+    if (gz) {
+      for (int i = c.tid; i < c.P; i += c.nthr) gz[i] = 0.0;
+    }
+    TF_SYNC();
+#ifndef SCAML_HOST_EMUL
+    return __builtin_nan("");
+#else
+    return NAN;
+#endif
+  }
+  // ---- pivots, v = L^-1 r, quad, logdet ----
+  double ld = 0.0;
+  for (int k = c.tid; k < n; k += c.nthr) {
+    const double pv = c.Ap[tf_idxL(k, k)];
+    const double r = 1.0 / sqrt(pv);
+    c.piv[k] = pv;
+    c.rs[k] = r;
+    c.vv[k] = c.Ap[tf_idxL(n, k)] * r;
+    ld += log(pv);
+  }
+  // log priors ride in the same reduction
+  double lp = 0.0;
+  for (int i = c.tid; i < D + 2; i += c.nthr) lp += tf_prior_logp(i < D ? sp.ls_prior : (i == D ? sp.os_prior : sp.nz_prior), c.theta[i]);
+  for (int i = c.tid; i < T; i += c.nthr) lp += tf_prior_logp(sp.w_prior, c.w[i]);
+  const double quad = -c.Ap[tf_idxL(n, n)];
+  const double logdet = tf_block_sum(c, ld);
+  const double logprior = tf_block_sum(c, lp);
+  const double value = (-0.5 * (quad + logdet + n * 1.8378770664093453) + logprior) / n;
+  if (!gz) return value;
+  // ---- U = L^-T scaled: U[j][k] = (L^-1)[k][j], rows j, columns k >= j ----
+  for (int j = c.wave; j < n; j += c.nwave) {
+    const int b0 = tf_rowT(j, n);
+    for (int k = j + c.lane; k < n; k += TF_LANES) c.Tp[b0 + k] *= c.rs[k];
+  }
+  TF_SYNC();
+  // alpha_a = sum_{k >= a} U[a][k] v[k]
+  for (int a = c.wave; a < n; a += c.nwave) {
+    const int b0 = tf_rowT(a, n);
+    double acc = 0.0;
+    for (int k = a + c.lane; k < n; k += TF_LANES) acc += c.Tp[b0 + k] * c.vv[k];
+    acc = tf_wave_sum(acc);
+    if (tf_last_lane(c)) c.alpha[a] = acc;
+  }
+  TF_SYNC();
+  // G = (alpha alpha^T - K^-1) / 2, off-diagonal elements doubled (they stand for both halves), into Ap
+  for (int e = c.tid; e < E; e += c.nthr) {
+    int a, b;
+    tf_decode(e, a, b);
+    const int ba = tf_rowT(a, n), bb = tf_rowT(b, n);
+    double s = 0.0;
+    for (int k = a; k < n; ++k) s += c.Tp[ba + k] * c.Tp[bb + k];
+    const double g = 0.5 * (c.alpha[a] * c.alpha[b] - s);
+    c.Ap[e] = a == b ? g : 2.0 * g;
+  }
+  TF_SYNC();
+  const double inv_n = 1.0 / n;
+  // ---- d / d w_i: one wave per task ----
+  for (int i = c.wave; i < T; i += c.nwave) {
+    const double* cp = p.covs_p + (size_t)i * E;
+    const double* mp = p.means_t + (size_t)i * n;
+    double acc = 0.0, accm = 0.0;
+    for (int e = c.lane; e < E; e += TF_LANES) acc += c.Ap[e] * cp[e];
+    for (int a = c.lane; a < n; a += TF_LANES) accm += c.alpha[a] * mp[a];
+    const double wi = c.w[i];
+    const double tot = tf_wave_sum(acc * (2.0 * wi * inv_s2) + accm * inv_s);
+    if (tf_last_lane(c)) gz[D + 2 + i] = (tot + tf_prior_dlogp(sp.w_prior, wi)) * inv_n;
+  }
+  // ---- d / d (lengthscales, outputscale, noise) ----
+  double gl[TARGET_FIT_DMAX];
+#pragma unroll
+  for (int d = 0; d < TARGET_FIT_DMAX; ++d) gl[d] = 0.0;
+  double gos = 0.0, gnz = 0.0;
+  for (int e = c.tid; e < E; e += c.nthr) {
+    int a, b;
+    tf_decode(e, a, b);
+    const double ge = c.Ap[e];
+    if (a == b) {
+      gos += ge;
+      gnz += ge;
+    } else {
+      double df2[TARGET_FIT_DMAX];
+      double d2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < TARGET_FIT_DMAX; ++d) {
+        df2[d] = 0.0;
+        if (d < D) {
+          const double df = (c.Xs[a * D + d] - c.Xs[b * D + d]) * c.invl[d];
+          df2[d] = df * df;
+          d2 += df2[d];
+        }
+      }
+      double kk, dk;
+      tf_kernel(c.kind, d2, kk, dk);
+      gos += ge * kk;
+      const double h = -2.0 * ge * os * dk;   // d d2 / d l_d = -2 df_d^2 / l_d
+#pragma unroll
+      for (int d = 0; d < TARGET_FIT_DMAX; ++d) gl[d] += h * df2[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < TARGET_FIT_DMAX; ++d) {
+    if (d < D) {
+      const double s = tf_wave_sum(gl[d]);
+      if (tf_last_lane(c)) c.part[c.wave * (TARGET_FIT_DMAX + 2) + d] = s;
+    }
+  }
+  {
+    const double s1 = tf_wave_sum(gos), s2 = tf_wave_sum(gnz);
+    if (tf_last_lane(c)) {
+      c.part[c.wave * (TARGET_FIT_DMAX + 2) + TARGET_FIT_DMAX] = s1;
+      c.part[c.wave * (TARGET_FIT_DMAX + 2) + TARGET_FIT_DMAX + 1] = s2;
+    }
+  }
+  TF_SYNC();
+  for (int q = c.tid; q < D + 2; q += c.nthr) {
+    const int slot = q < D ? q : (TARGET_FIT_DMAX + (q - D));
+    double s = 0.0;
+    for (int v = 0; v < c.nwave; ++v) s += c.part[v * (TARGET_FIT_DMAX + 2) + slot];
+    const double th = c.theta[q];
+    if (q < D) s *= c.invl[q];   // (the 1 / l_d of d d2 / d l_d)
+    const TargetPrior& pr = q < D ? sp.ls_prior : (q == D ? sp.os_prior : sp.nz_prior);
+    gz[q] = (s + tf_prior_dlogp(pr, th)) * c.dth[q] * inv_n;
+  }
+  TF_SYNC();
+  return value;
+}
+
+// ---- the optimiser: minimise f = -mll over z, w >= w_lower ----------------------------------------------------------------
+TF_DEV double tf_dot(const TfCtx& c, const double* a, const double* b) {
+  double s = 0.0;
+  for (int i = c.tid; i < c.P; i += c.nthr) s += a[i] * b[i];
+  return tf_block_sum(c, s);
+}
+
+TF_DEV bool tf_finite(double x) { return x - x == 0.0; }
+
+TF_DEV void tf_lbfgs(const TfCtx& c, const TargetFitParams& p, int prob) {
+  const int P = c.P, D = c.D, H = p.history;
+  double* ws = p.workspace + (size_t)prob * (6 + 2 * H) * P;
+  double *x = p.z + (size_t)prob * P, *g = ws, *xn = ws + P, *gn = ws + 2 * P, *dvec = ws + 3 * P, *q = ws + 4 * P, *mask = ws + 5 * P;
+  double* S = ws + 6 * P;
+  double* Y = S + (size_t)H * P;
+  double* rho = c.sc + 8;                       // [H]
+  double* al = c.sc + 8 + TARGET_FIT_HMAX;      // [H]
+  const double lb = p.spec.w_lower;
+  const double c1 = 1e-4;
+  // start inside the box
+  for (int i = D + 2 + c.tid; i < P; i += c.nthr) x[i] = fmax(x[i], lb);
+  TF_SYNC();
+  int32_t* info_out = p.info ? p.info + prob : nullptr;
+  double* jit_out = p.jitter ? p.jitter + prob : nullptr;
+  double f = -tf_eval(c, p, x, g, info_out, jit_out);
+  for (int i = c.tid; i < P; i += c.nthr) g[i] = -g[i];
+  TF_SYNC();
+  int n_eval = 1, it = 0, status = 0, hist = 0, head = 0;   // status 0 running/maxiter, 1 converged (gradient), 2 converged (decrease), 3 line search failed, 4 bad start
+  if (!tf_finite(f)) status = 4;
+  while (status == 0 && it < p.max_iter) {
+    ++it;
+    // free variables: everything except weights sitting on the bound whose gradient pushes outwards
+    for (int i = c.tid; i < P; i += c.nthr) {
+      const bool fixed = i >= D + 2 && x[i] <= lb && g[i] > 0.0;
+      mask[i] = fixed ? 0.0 : 1.0;
+      q[i] = fixed ? 0.0 : g[i];
+    }
+    TF_SYNC();
+    // two-loop recursion, newest pair first (pair h lives in slot (head - 1 - h) mod H)
+    for (int h = 0; h < hist; ++h) {
+      const int slot = (head - 1 - h + 2 * H) % H;
+      const double a = rho[slot] * tf_dot(c, S + (size_t)slot * P, q);
+      if (c.tid == 0) al[slot] = a;
+      for (int i = c.tid; i < P; i += c.nthr) q[i] -= a * Y[(size_t)slot * P + i];
+      TF_SYNC();
+    }
+    double gamma = 1.0;
+    if (hist > 0) {
+      const int slot = (head - 1 + H) % H;
+      const double yy = tf_dot(c, Y + (size_t)slot * P, Y + (size_t)slot * P);
+      if (yy > 0.0) gamma = 1.0 / (rho[slot] * yy);
+    }
+    for (int i = c.tid; i < P; i += c.nthr) q[i] *= gamma;
+    TF_SYNC();
+    for (int h = hist - 1; h >= 0; --h) {
+      const int slot = (head - 1 - h + 2 * H) % H;
+      const double b = rho[slot] * tf_dot(c, Y + (size_t)slot * P, q);
+      const double a = al[slot];
+      for (int i = c.tid; i < P; i += c.nthr) q[i] += (a - b) * S[(size_t)slot * P + i];
+      TF_SYNC();
+    }
+    for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -q[i] * mask[i];
+    TF_SYNC();
+    double gd = tf_dot(c, g, dvec);
+    double t = 1.0;
+    if (!(gd < 0.0) || hist == 0) {   // first step / not a descent direction: steepest descent, scipy-like first step length
+      for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -g[i] * mask[i];
+      TF_SYNC();
+      gd = tf_dot(c, g, dvec);
+      const double gn2 = -gd;
+      t = fmin(1.0, 1.0 / sqrt(fmax(gn2, 1e-24)));
+      if (!(gd < 0.0)) {   // projected gradient is zero: converged
+        status = 1;
+        break;
+      }
+    }
+    // projected backtracking line search
+    bool accepted = false;
+    double fn = f;
+    for (int ls = 0; ls < p.max_ls; ++ls) {
+      for (int i = c.tid; i < P; i += c.nthr) {
+        double v = x[i] + t * dvec[i];
+        if (i >= D + 2) v = fmax(v, lb);
+        xn[i] = v;
+      }
+      TF_SYNC();
+      fn = -tf_eval(c, p, xn, gn, nullptr, nullptr);
+      ++n_eval;
+      double dec = 0.0;
+      for (int i = c.tid; i < P; i += c.nthr) dec += g[i] * (xn[i] - x[i]);
+      dec = tf_block_sum(c, dec);
+      if (tf_finite(fn) && fn <= f + c1 * dec) {
+        accepted = true;
+        break;
+      }
+      t *= 0.5;
+    }
+    if (!accepted) {
+      status = 3;
+      break;
+    }
+    // curvature pair (gn holds +d mll/dz: negate on the fly)
+    double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
+    const int slot = head;
+    for (int i = c.tid; i < P; i += c.nthr) {
+      const double gi = -gn[i];
+      const double s = xn[i] - x[i], y = gi - g[i];
+      sy += s * y;
+      ss += s * s;
+      yy += y * y;
+      q[i] = gi;   // (q is free again: new gradient staged here)
+    }
+    sy = tf_block_sum(c, sy);
+    ss = tf_block_sum(c, ss);
+    yy = tf_block_sum(c, yy);
+    const bool push = sy > 1e-10 * sqrt(ss) * sqrt(yy);
+    for (int i = c.tid; i < P; i += c.nthr) {
+      const double gi = q[i];
+      if (push) {
+        S[(size_t)slot * P + i] = xn[i] - x[i];
+        Y[(size_t)slot * P + i] = gi - g[i];
+      }
+      x[i] = xn[i];
+      g[i] = gi;
+      // projected gradient (scipy's pgtol test): |P(x - g) - x|
+      double st = x[i] - gi;
+      if (i >= D + 2) st = fmax(st, lb);
+      pg = fmax(pg, fabs(st - x[i]));
+    }
+    if (push) {
+      if (c.tid == 0) rho[slot] = 1.0 / sy;
+      head = (head + 1) % H;
+      if (hist < H) ++hist;
+    }
+    pg = tf_block_max(c, pg);
+    const double rel = (f - fn) / fmax(fmax(fabs(f), fabs(fn)), 1.0);
+    f = fn;
+    if (pg <= p.gtol) status = 1;
+    else if (rel <= p.ftol && it > 1) status = 2;
+  }
+  // the objective (and its status) at the point that is kept
+  const double val = tf_eval(c, p, x, nullptr, info_out, jit_out);
+  if (c.tid == 0) {
+    p.value[prob] = val;
+    if (p.stats) {
+      p.stats[4 * prob + 0] = it;
+      p.stats[4 * prob + 1] = n_eval + 1;
+      p.stats[4 * prob + 2] = status;
+      p.stats[4 * prob + 3] = 0;
+    }
+  }
+}
+
+TF_DEV void tf_carve(TfCtx& c, double* lds, int n, int T, int D, int nwave) {
+  double* q = lds;
+  c.Ap = q; q += (n + 1) * (n + 2) / 2;
+  c.Tp = q; q += n * (n + 1) / 2;
+  c.Xs = q; q += n * D;
+  c.col = q; q += 2 * (n + 1);
+  c.piv = q; q += n;
+  c.rs = q; q += n;
+  c.alpha = q; q += n;
+  c.vv = q; q += n;
+  c.w = q; q += T;
+  c.w2 = q; q += T;
+  c.theta = q; q += D + 2;
+  c.dth = q; q += D + 2;
+  c.invl = q; q += D;
+  c.part = q; q += nwave * (TARGET_FIT_DMAX + 2);
+  c.red = q; q += nwave;
+  c.sc = q; q += 8 + 2 * TARGET_FIT_HMAX;
+}
+
+TF_DEV void tf_main(TfCtx& c, const TargetFitParams& p, int prob) {
+  for (int i = c.tid; i < c.n * c.D; i += c.nthr) c.Xs[i] = p.X[i];
+  TF_SYNC();
+  if (p.mode == 0) {
+    const double v = tf_eval(c, p, p.z + (size_t)prob * c.P, p.grad + (size_t)prob * c.P, p.info + prob, p.jitter ? p.jitter + prob : nullptr);
+    if (c.tid == 0) p.value[prob] = v;
+  } else {
+    tf_lbfgs(c, p, prob);
+  }
+}
+
+#ifndef SCAML_HOST_EMUL
+extern "C" __global__ __launch_bounds__(512) void scaml_target_fit_kernel(TargetFitParams p) {
+  extern __shared__ double tf_lds[];
+  TfCtx c;
+  c.tid = threadIdx.x;
+  c.nthr = blockDim.x;
+  c.lane = threadIdx.x & 63;
+  c.wave = threadIdx.x >> 6;
+  c.nwave = blockDim.x >> 6;
+  c.n = p.n; c.T = p.T; c.D = p.D; c.P = p.D + 2 + p.T; c.E = p.n * (p.n + 1) / 2; c.kind = p.kind;
+  tf_carve(c, tf_lds, p.n, p.T, p.D, c.nwave);
+  tf_main(c, p, blockIdx.x);
+}
+#endif
+
+}  // namespace scaml

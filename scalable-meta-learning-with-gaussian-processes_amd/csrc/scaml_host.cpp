@@ -16,6 +16,8 @@
 #include "../../include/scaml_gp.h"
 #include "gp_fit_params.h"
 #include "gp_posterior_params.h"
+#include "gp_target_params.h"
+#include <math.h>
 
 extern "C" const unsigned char scaml_hsaco_blob[];   // generated: lib/hsaco_blob.c
 extern "C" const unsigned long scaml_hsaco_blob_len;
@@ -54,6 +56,7 @@ struct Module {
   hipFunction_t mllgrad[2] = {nullptr, nullptr};
   hipFunction_t tgt_assemble[2] = {nullptr, nullptr};
   hipFunction_t tgt_finish = nullptr;
+  hipFunction_t tgt_fit = nullptr;
   hipFunction_t blk_round = nullptr, blk_finish = nullptr;
   hipFunction_t blk_solve[2][2] = {}, blk_syrk[2] = {nullptr, nullptr};   // solve: [kind][D <= 8]
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
@@ -120,6 +123,8 @@ struct Module {
       if ((e = hipModuleGetFunction(&tgt_assemble[kind], mod, name)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&tgt_finish, mod, "scaml_target_finish_kernel")) != hipSuccess) return e;
+    if ((e = hipModuleGetFunction(&tgt_fit, mod, "scaml_target_fit_kernel")) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)tgt_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&blk_round, mod, "scaml_blocked_round_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&blk_finish, mod, "scaml_blocked_finish_kernel")) != hipSuccess) return e;
     for (int kind = 0; kind < 2; ++kind) {
@@ -682,6 +687,94 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
   e = hipModuleLaunchKernel(m.tgt_finish, (unsigned)((M + 127) / 128), 1, 1, 128, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_finish)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
+}
+
+// ---- (8) target GP: objective + gradient, and the whole L-BFGS refit, in one launch (csrc/gp_target_fit.hip) -------------
+namespace {
+constexpr int kTargetFitThreads = 512;
+size_t target_fit_lds_doubles(int n, int T, int D) {
+  const size_t nw = kTargetFitThreads / 64;
+  return (size_t)(n + 1) * (n + 2) / 2 + (size_t)n * (n + 1) / 2 + (size_t)n * D + 2 * (size_t)(n + 1) + 4 * (size_t)n + 2 * (size_t)T +
+         2 * (size_t)(D + 2) + D + nw * (scaml::TARGET_FIT_DMAX + 2) + nw + 8 + 2 * scaml::TARGET_FIT_HMAX;
+}
+int target_spec_from_host(const double* spec, scaml::TargetSpec& sp) {
+  sp.ls_lo = spec[0]; sp.ls_hi = spec[1]; sp.os_lo = spec[2]; sp.os_hi = spec[3]; sp.nz_lo = spec[4]; sp.nz_hi = spec[5];
+  if (!(sp.ls_hi > sp.ls_lo) || !(sp.os_hi > sp.os_lo) || !(sp.nz_hi > sp.nz_lo)) return SCAML_E_BADARG;
+  scaml::TargetPrior* pr[4] = {&sp.ls_prior, &sp.os_prior, &sp.nz_prior, &sp.w_prior};
+  for (int q = 0; q < 4; ++q) {
+    const int kind = (int)spec[6 + 3 * q];
+    const double p1 = spec[7 + 3 * q], p2 = spec[8 + 3 * q];
+    if (kind < 0 || kind > 2) return SCAML_E_BADARG;
+    if (kind == 1 && !(p1 > 0.0 && p2 > 0.0)) return SCAML_E_BADARG;
+    if (kind == 2 && !(p2 > 0.0)) return SCAML_E_BADARG;
+    pr[q]->kind = kind; pr[q]->pad_ = 0; pr[q]->p1 = p1; pr[q]->p2 = p2;
+    pr[q]->c0 = kind == 1 ? p1 * log(p2) - lgamma(p1) : (kind == 2 ? -log(p2) - 0.9189385332046727 : 0.0);
+  }
+  sp.w_lower = spec[18];
+  return SCAML_OK;
+}
+int target_fit_launch(scaml::TargetFitParams& p, void* stream) {
+  if (p.B < 0 || p.n < 1 || p.T < 1 || p.D < 1) return SCAML_E_BADARG;
+  if (!p.means_t || !p.covs_p || !p.X || !p.y || !p.z || !p.value || !p.info) return SCAML_E_BADARG;
+  if (p.kind != SCAML_KIND_RBF && p.kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (!(p.s_all > 0.0)) return SCAML_E_BADARG;
+  if (p.D > scaml::TARGET_FIT_DMAX) return SCAML_E_TOOLARGE;
+  const size_t lds = target_fit_lds_doubles(p.n, p.T, p.D) * sizeof(double);
+  if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
+  if (p.B == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  size_t psize = sizeof(p);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
+  e = hipModuleLaunchKernel(m.tgt_fit, (unsigned)p.B, 1, 1, kTargetFitThreads, 1, 1, (unsigned)lds, (hipStream_t)stream, nullptr, config);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_fit)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+}  // namespace
+
+int scaml_target_fit_max_d(void) { return scaml::TARGET_FIT_DMAX; }
+
+int scaml_target_fit_max_n(int T, int D) {
+  if (T < 1 || D < 1 || D > scaml::TARGET_FIT_DMAX) return 0;
+  int n = 0;
+  while (n < 4096 && target_fit_lds_doubles(n + 1, T, D) * sizeof(double) <= 160 * 1024) ++n;
+  return n;
+}
+
+long long scaml_target_fit_workspace_doubles(int B, int T, int D, int history) {
+  if (B < 0 || T < 1 || D < 1 || history < 1) return 0;
+  return (long long)B * (6 + 2 * (long long)history) * (D + 2 + T);
+}
+
+int scaml_target_mll_f64(const double* means_t, const double* covs_packed, const double* X, const double* y, double m_all, double s_all,
+                         const double* spec_host, const double* z, int B, int n, int T, int D, int kind, double* value, double* grad,
+                         int32_t* info, double* jitter_used, void* stream) {
+  if (!spec_host || !grad) return SCAML_E_BADARG;
+  scaml::TargetFitParams p{};
+  p.means_t = means_t; p.covs_p = covs_packed; p.X = X; p.y = y; p.m_all = m_all; p.s_all = s_all;
+  const int rc = target_spec_from_host(spec_host, p.spec);
+  if (rc != SCAML_OK) return rc;
+  p.z = const_cast<double*>(z); p.value = value; p.grad = grad; p.info = info; p.jitter = jitter_used;
+  p.B = B; p.n = n; p.T = T; p.D = D; p.kind = kind; p.mode = 0; p.history = 1; p.max_ls = 0;
+  return target_fit_launch(p, stream);
+}
+
+int scaml_target_fit_f64(const double* means_t, const double* covs_packed, const double* X, const double* y, double m_all, double s_all,
+                         const double* spec_host, double* z, int B, int n, int T, int D, int kind, int max_iter, int history, double gtol,
+                         double ftol, double* value, int32_t* info, double* jitter_used, int32_t* stats, double* workspace,
+                         long long workspace_doubles, void* stream) {
+  if (!spec_host || !workspace) return SCAML_E_BADARG;
+  if (max_iter < 0 || history < 1 || history > scaml::TARGET_FIT_HMAX) return SCAML_E_BADARG;
+  if (workspace_doubles < scaml_target_fit_workspace_doubles(B, T, D, history)) return SCAML_E_BADARG;
+  scaml::TargetFitParams p{};
+  p.means_t = means_t; p.covs_p = covs_packed; p.X = X; p.y = y; p.m_all = m_all; p.s_all = s_all;
+  const int rc = target_spec_from_host(spec_host, p.spec);
+  if (rc != SCAML_OK) return rc;
+  p.z = z; p.value = value; p.grad = nullptr; p.info = info; p.jitter = jitter_used; p.workspace = workspace; p.stats = stats;
+  p.B = B; p.n = n; p.T = T; p.D = D; p.kind = kind; p.mode = 1; p.max_iter = max_iter; p.history = history; p.max_ls = 20;
+  p.gtol = gtol; p.ftol = ftol;
+  return target_fit_launch(p, stream);
 }
 
 // Developer switch: 1 routes scaml_mll_backward_f64 through the two-launch path (L^-1 in the workspace, then the K^-1 tile kernel)

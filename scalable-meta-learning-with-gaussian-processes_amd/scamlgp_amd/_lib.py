@@ -117,6 +117,18 @@ def _load() -> ctypes.CDLL:
     lib.scaml_target_assemble_f64.argtypes = [_dp] * 6 + [c_double, c_double, c_int, c_int, c_int, c_int] + [_dp] * 5 + [c_void_p]
     lib.scaml_target_finish_f64.restype = c_int
     lib.scaml_target_finish_f64.argtypes = [_dp] * 5 + [c_double, c_double, c_double, _dp, c_int, c_int, _dp, _dp, c_void_p]
+    lib.scaml_target_fit_max_n.restype = c_int
+    lib.scaml_target_fit_max_n.argtypes = [c_int, c_int]
+    lib.scaml_target_fit_max_d.restype = c_int
+    lib.scaml_target_fit_max_d.argtypes = []
+    lib.scaml_target_fit_workspace_doubles.restype = ctypes.c_longlong
+    lib.scaml_target_fit_workspace_doubles.argtypes = [c_int, c_int, c_int, c_int]
+    host_spec = ctypes.POINTER(c_double)   # (the one host pointer of the ABI: 19 doubles read during the call)
+    lib.scaml_target_mll_f64.restype = c_int
+    lib.scaml_target_mll_f64.argtypes = [_dp] * 4 + [c_double, c_double, host_spec, _dp] + [c_int] * 5 + [_dp] * 4 + [c_void_p]
+    lib.scaml_target_fit_f64.restype = c_int
+    lib.scaml_target_fit_f64.argtypes = ([_dp] * 4 + [c_double, c_double, host_spec, _dp] + [c_int] * 7 + [c_double, c_double] + [_dp] * 5
+                                         + [ctypes.c_longlong, c_void_p])
     lib.scaml_debug_force_two_launch_grad.restype = c_int
     lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib
@@ -151,6 +163,11 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_linv_cov_f64",
     "scaml_target_assemble_f64",
     "scaml_target_finish_f64",
+    "scaml_target_fit_max_n",
+    "scaml_target_fit_max_d",
+    "scaml_target_fit_workspace_doubles",
+    "scaml_target_mll_f64",
+    "scaml_target_fit_f64",
 )
 
 

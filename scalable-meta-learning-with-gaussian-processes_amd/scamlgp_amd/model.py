@@ -273,6 +273,8 @@ class SourceGP:
         return (self._stack.X[self._index, : self._stack.n_list[self._index]],)
 
     def posterior(self, x: torch.Tensor) -> _Posterior:
+        if x.dim() > 2:
+            raise ValueError("SourceGP.posterior takes x (M, D): batched inputs go through ScaMLGP.posterior / forward")
         x2 = x.reshape(-1, x.shape[-1])
         M = x2.shape[0]
         p = self._stack.posterior(x2, cov_first=M)
@@ -360,6 +362,8 @@ def _compute_target_prior(x: torch.Tensor, source_gps: List[SourceGP], weights: 
     if len(source_gps) != len(weights):
         raise ValueError(f"The number of source GPs, {len(source_gps)}, does not equal the number of weights, {len(weights)}")
     stack, idx = _stack_of(source_gps)
+    if x.dim() > 2:
+        raise ValueError("_compute_target_prior takes x (n, D): batched inputs go through ScaMLGP.posterior / forward")
     x2 = x.reshape(-1, x.shape[-1]).to(stack.device, torch.float64)
     M = x2.shape[0]
     p = stack.posterior(x2, cov_first=M)
@@ -403,6 +407,21 @@ def psd_safe_cholesky(A: torch.Tensor, max_tries: int = 3) -> torch.Tensor:
         if not bool(info.any()):
             return L
     raise ops.NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter:.1e}.")
+
+
+def _split_batch(X: torch.Tensor, D: int):
+    """X (..., q, D) -> (flat (M, D), batch_shape or None, q): botorch hands models ``batch_shape x q x d`` inputs
+    (scamlgp/model.py:359-384 keeps the batch dimensions); the kernels take one flat list of M = prod(batch) * q points."""
+    if X.dim() <= 2:
+        return X.reshape(-1, D), None, X.reshape(-1, D).shape[0]
+    return X.reshape(-1, D), tuple(X.shape[:-2]), int(X.shape[-2])
+
+
+def _batch_blocks(cov: torch.Tensor, batch, q: int) -> torch.Tensor:
+    """The per-batch q x q diagonal blocks of a joint (M, M) covariance, shaped (*batch, q, q)."""
+    B = cov.shape[0] // q
+    blocks = cov.reshape(B, q, B, q).diagonal(dim1=0, dim2=2).permute(2, 0, 1)
+    return blocks.reshape(*batch, q, q)
 
 
 class _LazyMVN:
@@ -586,7 +605,7 @@ class ScaMLGP:
     def forward(self, x: torch.Tensor) -> _MVN:
         """scamlgp/model.py:359-384.  Training: cached source terms at train_X; eval: pruned weights and a
         fresh batched source posterior at x.  Both in the standardised target space, plus k_t(x, x)."""
-        x = torch.as_tensor(x, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device)
+        x, batch, q = _split_batch(torch.as_tensor(x, dtype=torch.float64).to(self.device), self._stack.D)
         w = self.weights
         if self.training:
             mean = self.source_means @ w
@@ -598,6 +617,8 @@ class ScaMLGP:
             mean = (mean - self.m_all) / self.s_all
             cov = cov / self.s_all ** 2
         cov = cov + _kernel_torch(x, x, self.theta, self.kind)
+        if batch is not None and not self.training:   # (batch, q, D) input: independent q-point joints, one per batch element
+            return _MVN(mean.reshape(*batch, q), _batch_blocks(cov, batch, q))
         return _MVN(mean, cov)
 
     __call__ = forward
@@ -622,6 +643,28 @@ class ScaMLGP:
         val = val + self.spec.log_prior(theta) + self.weights_prior.log_prob(w).sum()
         return val / self.n
 
+    def target_problem(self) -> Optional[ops.TargetFitProblem]:
+        """The training set in the layouts of the library's target-fit kernel (built once; None if the kernel does not take
+        this shape -- more target points than its LDS holds, D > 16 -- and the torch objective ``mll`` is all there is)."""
+        if getattr(self, "_tprob", None) is None:
+            if self.n < 1 or not ops.TargetFitProblem.supported(self.n, self.T, self._stack.D):
+                return None
+            self._tprob = ops.TargetFitProblem(self.source_means, self.source_covs, self.train_X, self.train_targets, self._m_all_f,
+                                               self._s_all_f, self.spec, self.weights_prior, self.weights_lower_bound, self.kind)
+        return self._tprob
+
+    def mll_and_grad(self, z: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The training objective ``mll`` and its analytic gradient w.r.t. z = [raw_theta || raw_weights] for the rows of z
+        (B, D + 2 + T) (default: the model's current parameters, B = 1): ONE launch of scaml_target_mll_f64 instead of torch
+        autograd through ~100 small kernels.  Returns (value (B,), grad (B, P))."""
+        prob = self.target_problem()
+        if prob is None:
+            raise ValueError("the target-fit kernel does not take this shape; use ScaMLGP.mll with torch autograd")
+        if z is None:
+            z = torch.cat([self.raw_theta, self.raw_weights]).unsqueeze(0)
+        out = ops.target_mll(prob, z.to(self.device, torch.float64).reshape(-1, prob.P))
+        return out["value"], out["grad"]
+
     def _joint(self, Xq: torch.Tensor, full: bool):
         """Standardised joint prior over cat(train_X, Xq) (A8, A10) from ONE source-posterior launch: mean (n + M,),
         the n x (n + M) covariance block (or the whole (n + M)^2 one with ``full``) and the query diagonal."""
@@ -641,8 +684,9 @@ class ScaMLGP:
         """Target posterior at X (M, D) in original units (A10).  The source prior is evaluated ONCE at
         cat(train_X, X) -- train block, cross block and query diagonal -- instead of once per query as the
         reference does.  ``.mvn.covariance_matrix`` (the joint (M, M) covariance) costs a second
-        launch with the full query block and is only computed when read."""
-        Xq = torch.as_tensor(X, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device)
+        launch with the full query block and is only computed when read.  X (M, D): M points, ``.mean`` (M, 1), joint (M, M)
+        covariance.  X (*batch, q, D): ``.mean`` / ``.variance`` (*batch, q, 1), ``.mvn.covariance_matrix`` (*batch, q, q)."""
+        Xq, batch, q = _split_batch(torch.as_tensor(X, dtype=torch.float64).to(self.device), self._stack.D)
         n = self.n
         if 1 <= n <= ops.fit_max_n():
             # the library's target-GP path: weighted source sums at cat(train_X, Xq), then assemble -> jittered Cholesky
@@ -681,4 +725,11 @@ class ScaMLGP:
                 S = S + th[-1] * torch.eye(S.shape[0], dtype=torch.float64, device=self.device)
             return self.s_all ** 2 * S
 
+        if batch is not None:
+            # botorch's batch_shape x q x d convention (scamlgp/model.py:359-384 keeps the batch dimensions): mean / variance
+            # (*batch, q, 1), covariance (*batch, q, q) -- one joint per batch element, NOT one joint over all points.  q = 1 (what
+            # optimize_acqf sends to an analytic acquisition function) needs no joint at all.
+            if q == 1:
+                return TargetPosterior(mu_o.reshape(*batch, 1), var_o.reshape(*batch, 1), lambda: var_o.reshape(*batch, 1, 1))
+            return TargetPosterior(mu_o.reshape(*batch, q), var_o.reshape(*batch, q), lambda: _batch_blocks(full_cov(), batch, q))
         return TargetPosterior(mu_o, var_o, full_cov)

@@ -612,6 +612,95 @@ def fused_mll(X: torch.Tensor, y: torch.Tensor, theta: torch.Tensor, kind: int,
     return FusedMLL.apply(X, y, theta, kind, n_points, out)
 
 
+
+# ---- (8) target GP: objective + gradient / whole refit in one launch -------------------------------------------------------
+class TargetFitProblem:
+    """Device-resident inputs of ``scaml_target_mll_f64`` / ``scaml_target_fit_f64`` for ONE ScaMLGP training set: the source
+    terms cached at construction (scamlgp/model.py:279-289) in the kernel's layouts -- means (T, n), covariances packed lower
+    (T, n (n + 1) / 2) --, the target inputs / standardised targets, the standardiser and the constraint / prior block.
+    Built once per model; every objective evaluation and the refit reuse it."""
+
+    def __init__(self, source_means: torch.Tensor, source_covs: torch.Tensor, train_X: torch.Tensor, train_targets: torch.Tensor,
+                 m_all: float, s_all: float, spec, weights_prior, weights_lower_bound: float, kind: int):
+        import ctypes
+
+        from . import hyper
+
+        n, T = source_means.shape
+        D = train_X.shape[-1]
+        self.n, self.T, self.D, self.kind = int(n), int(T), int(D), int(kind)
+        self.P = D + 2 + T
+        self.device = train_X.device
+        self.means_t = _check(source_means.transpose(0, 1), "source_means^T", (T, n))
+        ia, ib = torch.tril_indices(n, n, device=self.device)
+        self.covs_p = source_covs[ia, ib, :].transpose(0, 1).contiguous()          # (T, n (n + 1) / 2): plumbing, once per model
+        self.X = _check(train_X, "train_X", (n, D))
+        self.y = _check(train_targets, "train_targets", (n,))
+        self.m_all, self.s_all = float(m_all), float(s_all)
+
+        def prior(pr):
+            if pr is None:
+                return [0.0, 0.0, 0.0]
+            if isinstance(pr, hyper.GammaPrior):
+                return [1.0, pr.concentration, pr.rate]
+            if isinstance(pr, hyper.LogNormalPrior):
+                return [2.0, pr.loc, pr.scale]
+            raise TypeError(f"prior {type(pr).__name__} is not supported by the target-fit kernel")
+
+        vals = [spec.ls_constraint.lower, spec.ls_constraint.upper, spec.os_constraint.lower, spec.os_constraint.upper,
+                spec.noise_constraint.lower, spec.noise_constraint.upper, *prior(spec.ls_prior), *prior(spec.os_prior),
+                *prior(spec.noise_prior), *prior(weights_prior), float(weights_lower_bound)]
+        self.spec_host = (ctypes.c_double * 19)(*[float(v) for v in vals])
+
+    @staticmethod
+    def supported(n: int, T: int, D: int) -> bool:
+        return D <= _lib.lib.scaml_target_fit_max_d() and 1 <= n <= _lib.lib.scaml_target_fit_max_n(T, D)
+
+
+def target_mll(prob: TargetFitProblem, z: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """mll(z_b) and d mll / d z_b for the rows of z (B, D + 2 + T) = [raw lengthscales, raw outputscale, raw noise, weights]:
+    the ScaMLGP training objective of scamlgp/model.py:360-363 + utils.py:171-177 (priors included, divided by n) with its
+    analytic gradient, ONE launch of scaml_target_mll_f64.  Returns dict(value (B,), grad (B, P), info (B,), jitter (B,));
+    a matrix that is not positive definite even with jitter 1e-6 gives value NaN, info > 0 and a zero gradient."""
+    z = _check(z, "z", (z.shape[0], prob.P))
+    B = z.shape[0]
+    dev = prob.device
+    with torch.cuda.device(dev):
+        value = torch.empty((B,), dtype=torch.float64, device=dev)
+        grad = torch.empty((B, prob.P), dtype=torch.float64, device=dev)
+        info = torch.empty((B,), dtype=torch.int32, device=dev)
+        jit = torch.empty((B,), dtype=torch.float64, device=dev)
+        rc = _lib.lib.scaml_target_mll_f64(_ptr(prob.means_t), _ptr(prob.covs_p), _ptr(prob.X), _ptr(prob.y), prob.m_all, prob.s_all,
+                                           prob.spec_host, _ptr(z), B, prob.n, prob.T, prob.D, prob.kind, _ptr(value), _ptr(grad),
+                                           _ptr(info), _ptr(jit), _stream_handle())
+    _lib.check_rc(rc, "scaml_target_mll_f64")
+    return dict(value=value, grad=grad, info=info, jitter=jit)
+
+
+def target_fit(prob: TargetFitProblem, z0: torch.Tensor, max_iter: int = 200, history: int = 10, gtol: float = 1e-5,
+               ftol: float = 2.2e-9) -> Dict[str, torch.Tensor]:
+    """Maximise mll from every row of z0 (B, P) on the device: ONE launch of scaml_target_fit_f64 runs all B L-BFGS
+    optimisations (warm start + restarts of scamlgp/utils.py:184-199) to convergence -- no host round trip per evaluation.
+    Returns dict(z (B, P) optima, value (B,) mll there, info, jitter, stats (B, 4) = [iterations, evaluations, status, 0])."""
+    z = _check(z0, "z0", (z0.shape[0], prob.P)).clone()
+    B = z.shape[0]
+    dev = prob.device
+    with torch.cuda.device(dev):
+        value = torch.empty((B,), dtype=torch.float64, device=dev)
+        info = torch.empty((B,), dtype=torch.int32, device=dev)
+        jit = torch.empty((B,), dtype=torch.float64, device=dev)
+        stats = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        nws = int(_lib.lib.scaml_target_fit_workspace_doubles(B, prob.T, prob.D, history))
+        ws = torch.empty((max(nws, 1),), dtype=torch.float64, device=dev)
+        rc = _lib.lib.scaml_target_fit_f64(_ptr(prob.means_t), _ptr(prob.covs_p), _ptr(prob.X), _ptr(prob.y), prob.m_all, prob.s_all,
+                                           prob.spec_host, _ptr(z), B, prob.n, prob.T, prob.D, prob.kind, int(max_iter), int(history),
+                                           float(gtol), float(ftol), _ptr(value), _ptr(info), _ptr(jit), _ptr(stats), _ptr(ws), nws,
+                                           _stream_handle())
+        ws.record_stream(torch.cuda.current_stream(dev))
+    _lib.check_rc(rc, "scaml_target_fit_f64")
+    return dict(z=z, value=value, info=info, jitter=jit, stats=stats)
+
+
 def raise_if_not_psd(info: torch.Tensor) -> None:
     """Host-side check of the per-task status (one device->host sync)."""
     bad = torch.nonzero(info > 0).flatten()

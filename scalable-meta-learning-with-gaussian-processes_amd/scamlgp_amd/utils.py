@@ -18,6 +18,7 @@ import torch
 
 from . import dist as sdist
 from . import hyper
+from . import ops
 from .model import ScaMLGP, SourceGP, SourceGPStack
 
 logger = logging.getLogger("scamlgp_amd")
@@ -128,11 +129,10 @@ class _GraphedObjective:
         return self.host.numpy()
 
 
-def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200, use_graph: bool = True) -> None:
-    """Target GP: weights + kernel hyper-parameters by scipy L-BFGS-B (the weights carry the box bound
-    w >= 1e-10, scamlgp/model.py:334), objective and gradient from torch autograd on the device."""
-    if model.n == 0:
-        return
+def _fit_target_scipy(model: ScaMLGP, starts: torch.Tensor, maxiter: int, use_graph: bool):
+    """The refit where the library's target-fit kernel does not take the shape (n beyond its LDS, D > 16): scipy L-BFGS-B per
+    start point, objective and gradient from torch autograd on the device (``ScaMLGP.mll``), replayed from a HIP graph.
+    Returns (z (B, P), f (B,)) with f = -mll at the end points (inf for a failed run)."""
     D2, T = model.raw_theta.numel(), model.T
     bounds = [(None, None)] * D2 + [(model.weights_lower_bound, None)] * T
 
@@ -148,10 +148,8 @@ def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200, use_graph
             return float("inf"), np.zeros_like(z)
         return v, g.cpu().numpy()
 
-    # The objective is ~100 small launches per evaluation (kernel matrix, weighted sums, priors, their backward) around the
-    # library's factorisation: launch-bound (2.2 ms per evaluation at n = 80, T = 32, ~700 evaluations per fit).  Forward AND
-    # backward are captured once into a HIP graph on static buffers and replayed per evaluation; one device -> host copy of
-    # [value || gradient] per evaluation is the only synchronisation.
+    # ~100 small launches per evaluation: forward AND backward are captured once into a HIP graph on static buffers and replayed per
+    # evaluation; one device -> host copy of [value || gradient] per evaluation is the only synchronisation.
     graphed = _GraphedObjective(model, D2) if use_graph and model.device.type == "cuda" else None
 
     def fun(z: np.ndarray):
@@ -163,28 +161,55 @@ def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200, use_graph
             return float("inf"), np.zeros_like(z)
         return v, out[1:].copy()
 
-    def run(z0: np.ndarray):
+    zs, fs = [], []
+    for z0 in starts.cpu().numpy():
         r = scipy.optimize.minimize(fun, z0, jac=True, method="L-BFGS-B", bounds=bounds, options=dict(maxiter=maxiter))
-        return r.x, float(r.fun)
+        zs.append(torch.from_numpy(np.asarray(r.x, dtype=np.float64)))
+        fs.append(float(r.fun))
+    return torch.stack(zs), torch.tensor(fs, dtype=torch.float64)
 
-    best_val, best_state = float("inf"), model.state_dict()
-    z0 = torch.cat([model.raw_theta, model.raw_weights]).cpu().numpy()
-    for attempt in range(1 + num_restarts):
-        if attempt > 0:
-            th = model.spec.sample_prior((), model.raw_theta.numel() - 2, device=model.device)
+
+def _fit_target(model: ScaMLGP, num_restarts: int, maxiter: int = 200, use_graph: bool = True, use_kernel: bool = True) -> None:
+    """Target GP: weights + kernel hyper-parameters (scamlgp/optimizer.py:176-185 -> scamlgp/utils.py:139-212).  The warm start
+    and the ``num_restarts`` prior-sampled starts are ONE batch; ``scaml_target_fit_f64`` runs all their L-BFGS optimisations
+    (box bound w >= 1e-10, scamlgp/model.py:334) to convergence in one launch on the device; the best end point is kept.
+    On a sharded model rank 0 fits and broadcasts the result: every rank must hold the same weights and hyper-parameters (the
+    weighted sums the ranks all-reduce in ``_source_prior`` are built from them)."""
+    if model.n == 0:
+        return
+    shard = model._shard
+    D2, T = model.raw_theta.numel(), model.T
+    best = torch.zeros(D2 + T + 1, dtype=torch.float64, device=model.device)   # [state || ok]
+    if shard is None or shard.rank == 0:
+        starts = [torch.cat([model.raw_theta, model.raw_weights])]
+        for _ in range(num_restarts):
+            th = model.spec.sample_prior((), D2 - 2, device=model.device)
             w = model.weights_prior.sample((T,), device=model.device).clamp_min(model.weights_lower_bound)
-            z0 = torch.cat([model.spec.to_raw(th), w]).cpu().numpy()
-        z, val = run(z0)
-        if math.isfinite(val) and val < best_val:
-            best_val = val
-            zt = torch.tensor(z, dtype=torch.float64, device=model.device)
-            best_state = {"raw_theta": zt[:D2].clone(), "raw_weights": zt[D2:].clone()}
-        elif not math.isfinite(val):
-            logger.warning("Error occurred while optimizing the model hyperparameters; this restart will be skipped.")
-    if not math.isfinite(best_val):
+            starts.append(torch.cat([model.spec.to_raw(th), w]))
+        z0 = torch.stack(starts)
+        prob = model.target_problem() if (use_kernel and model.device.type == "cuda") else None
+        if prob is not None:
+            res = ops.target_fit(prob, z0, max_iter=maxiter)
+            z, f = res["z"], -res["value"]
+            f = torch.where(torch.isfinite(f) & (res["stats"][:, 2] != 4), f, torch.full_like(f, float("inf")))
+            model.last_fit_info = dict(stats=res["stats"], objective=res["value"])
+        else:
+            z, f = _fit_target_scipy(model, z0, maxiter, use_graph)
+            z, f = z.to(model.device), f.to(model.device)
+        n_failed = int(torch.isinf(f).sum())     # (the one host synchronisation of the refit)
+        if n_failed and n_failed < f.numel():
+            logger.warning("Error occurred while optimizing the model hyperparameters; %d restart(s) will be skipped.", n_failed)
+        if n_failed < f.numel():
+            best[:-1] = z[int(f.argmin())]
+            best[-1] = 1.0
+    if shard is not None and shard.world > 1:
+        import torch.distributed as dist
+
+        dist.broadcast(best, src=dist.get_global_rank(shard.group, 0) if shard.group is not None else 0, group=shard.group)
+    if float(best[-1]) != 1.0:
         raise ModelFittingError("Hyperparameter optimization failed for all attempts. Usually this indicates a problem with "
                                 "model's input data or hyperparameter priors definitions.")
-    model.load_state_dict(best_state)
+    model.load_state_dict({"raw_theta": best[:D2].clone(), "raw_weights": best[D2:-1].clone()})
 
 
 def optimize_marginal_likelihood(model: Union[SourceGPStack, ScaMLGP, Dict, SourceGP], num_restarts: int = 0, **fit_options):
@@ -203,6 +228,19 @@ def optimize_marginal_likelihood(model: Union[SourceGPStack, ScaMLGP, Dict, Sour
 
 
 # --- acquisition functions (to be MAXIMISED, for minimising the objective) -------------------------
+def _single_q(X: torch.Tensor) -> torch.Tensor:
+    """botorch's analytic acquisition functions take ``batch_shape x 1 x d`` (t_batch_mode_transform(expected_q=1)) and return
+    ``batch_shape`` values; a q > 1 batch is an error there and here.  X (M, D) -- this package's flat list of M points -- passes."""
+    if X.dim() > 2 and X.shape[-2] != 1:
+        raise ValueError(f"analytic acquisition functions take q = 1 (X of shape batch_shape x 1 x d), got q = {X.shape[-2]}")
+    return X
+
+
+def _drop_q(X: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    return v.squeeze(-1) if X.dim() > 2 else v
+
+
+
 class UpperConfidenceBound:
     """botorch UpperConfidenceBound(model, beta=9.0, maximize=False) (scamlgp/utils.py:215-224):
     value = -mu + sqrt(beta * var) per query point; X (M, D) -> (M,)."""
@@ -211,8 +249,8 @@ class UpperConfidenceBound:
         self.model, self.beta = model, beta
 
     def __call__(self, X: torch.Tensor) -> torch.Tensor:
-        mvn = self.model.posterior(X).mvn
-        return -mvn.mean + torch.sqrt(self.beta * mvn.variance.clamp_min(0.0))
+        mvn = self.model.posterior(_single_q(X)).mvn
+        return _drop_q(X, -mvn.mean + torch.sqrt(self.beta * mvn.variance.clamp_min(0.0)))
 
 
 class ExpectedImprovement:
@@ -223,9 +261,9 @@ class ExpectedImprovement:
         self.model, self.best_f = model, best_f
 
     def __call__(self, X: torch.Tensor) -> torch.Tensor:
-        mvn = self.model.posterior(X).mvn
+        mvn = self.model.posterior(_single_q(X)).mvn
         sigma = mvn.variance.clamp_min(1e-9).sqrt()
         u = -(mvn.mean - self.best_f) / sigma
         pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
         cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
-        return sigma * (pdf + u * cdf)
+        return _drop_q(X, sigma * (pdf + u * cdf))

@@ -191,3 +191,75 @@ def test_dimensions_beyond_the_blocked_limit_take_the_composed_path(device):
     assert not out["info"].cpu().any()
     torch.testing.assert_close(out["alpha"].cpu(), ref["alpha"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(out["mll"].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)
+
+
+@pytest.mark.parametrize("T", [11, 32])
+def test_blocked_fit_full_stack_task_groups(T, device):
+    """BASELINE configs[4]'s source shape at full stack (T = 32, N = 512, D = 6, Matern) and a T that is not a multiple of 8: more
+    than one task group per XCD in the strip solve (task = (idx / parts) * 8 + xcd), switched-off padding workgroups, the
+    320-workgroup Schur grid.  One ragged task, one task that needs the jitter ladder.  Against the composed two-block path on
+    every task, against the oracle on three, and through size-independent properties on all (L L^T = K + (noise + jitter) I,
+    (K + noise I) alpha = y)."""
+    N, D, kind = 512, 6, O.KIND_MATERN52
+    X, y, theta = _stack(T, N, D, 1000 + T)
+    n = torch.full((T,), N, dtype=torch.int32)
+    n[T - 2] = 389                                  # ragged: second block partly filled
+    X[3, 300:320] = X[3, 20:40]                     # duplicates across the two blocks ...
+    theta[3, D + 1] = -3e-9                         # ... under a slightly negative diagonal: needs the ladder
+    Xd, yd, thd, nd = X.to(device), y.to(device), theta.to(device), n.to(device)
+    out = ops.gp_fit_fused(Xd, yd, thd, kind, n_points=nd)
+    comp = _composed(Xd, yd, thd, kind, n_points=nd)
+    assert not out["info"].cpu().any() and not comp["info"].cpu().any()
+    assert out["jitter"].cpu().tolist() == comp["jitter"].cpu().tolist() and float(out["jitter"][3]) > 0.0
+    torch.testing.assert_close(out["L"], comp["L"], rtol=1e-8, atol=1e-10)
+    well = [t for t in range(T) if t != 3]     # (task 3 sits on a diagonal of ~1e-8 under duplicated points: condition ~1e10, alpha is
+    torch.testing.assert_close(out["alpha"][well], comp["alpha"][well], rtol=1e-6, atol=1e-8)   # held by the residual check below)
+    torch.testing.assert_close(out["mll"][well], comp["mll"][well], rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(out["mll"][3], comp["mll"][3], rtol=1e-5, atol=0)
+    for t in (0, T - 2):
+        k = int(n[t])
+        ref = O.gp_fit(X[t, :k], y[t, :k], theta[t], kind)
+        torch.testing.assert_close(out["L"][t, :k, :k].cpu(), ref["L"], rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(out["alpha"][t, :k].cpu(), ref["alpha"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)
+    # properties on every task, on the device
+    K = ops.kernel_matrix(Xd, thd, kind, add_noise=True)
+    L = torch.tril(out["L"])
+    for t in range(T):
+        k = int(n[t])
+        Kt = K[t, :k, :k] + float(out["jitter"][t]) * torch.eye(k, dtype=torch.float64, device=device)
+        Lt = L[t, :k, :k]
+        assert float((Lt @ Lt.T - Kt).abs().max()) <= 1e-10 * float(Kt.abs().max())
+        r = Kt @ out["alpha"][t, :k] - yd[t, :k]
+        assert float(r.abs().max()) <= 1e-6 * float(yd[t, :k].abs().max())
+        torch.testing.assert_close(out["logdet"][t], 2.0 * torch.log(torch.diagonal(Lt)).sum(), rtol=1e-10, atol=1e-8)
+
+
+def test_blocked_fit_ragged_with_uninitialised_outputs_through_the_c_abi(device):
+    """include/scaml_gp.h: rows / columns >= n_t of L are never written and may hold anything.  A caller that hands over L and
+    alpha buffers full of NaN bit patterns (what a C caller's uninitialised memory may be) gets finite results in the valid
+    part, through the raw entry point."""
+    T, N, D, kind = 4, 512, 4, O.KIND_RBF
+    X, y, theta = _stack(T, N, D, 31)
+    n = torch.tensor([512, 300, 256, 100], dtype=torch.int32)
+    Xd, yd, thd, nd = X.to(device), y.to(device), theta.to(device), n.to(device)
+    f64 = dict(dtype=torch.float64, device=device)
+    L = torch.full((T, N, N), float("nan"), **f64)
+    alpha = torch.full((T, N), float("nan"), **f64)
+    quad, logdet, mll, jit = (torch.empty(T, **f64) for _ in range(4))
+    info = torch.empty(T, dtype=torch.int32, device=device)
+    linv = torch.empty(T, N // 16, 16, 16, **f64)
+    nbytes = int(_lib.lib.scaml_gp_fit_blocked_workspace_bytes(T, N))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    rc = _lib.lib.scaml_gp_fit_blocked_f64(Xd.data_ptr(), yd.data_ptr(), thd.data_ptr(), nd.data_ptr(), None, T, N, D, kind, L.data_ptr(),
+                                           alpha.data_ptr(), quad.data_ptr(), logdet.data_ptr(), mll.data_ptr(), info.data_ptr(), jit.data_ptr(),
+                                           linv.data_ptr(), _lib.FIT_STORE_L, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert not info.cpu().any()
+    for t in range(T):
+        k = int(n[t])
+        ref = O.gp_fit(X[t, :k], y[t, :k], theta[t], kind)
+        torch.testing.assert_close(torch.tril(L[t, :k, :k]).cpu(), ref["L"], rtol=1e-7, atol=1e-9)
+        torch.testing.assert_close(alpha[t, :k].cpu(), ref["alpha"], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(mll[t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)

@@ -147,6 +147,6 @@ def test_bench_parent_refuses_missing_gpus(monkeypatch, capsys):
     import bench
 
     monkeypatch.delenv("SCAML_BENCH_REHEARSAL", raising=False)
-    args = argparse.Namespace(gpus=64, steps=1, warmup=0, step="fit", no_cpu_baseline=True)
+    args = argparse.Namespace(gpus=64, steps=1, warmup=0, step="fit", no_cpu_baseline=True, prewarm=0, total_tasks=0)
     assert bench.launch_ranks(args) == 2
     assert "needs 64 GPUs" in capsys.readouterr().err

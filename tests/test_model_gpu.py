@@ -279,3 +279,77 @@ def test_target_posterior_marks_a_failed_factorisation_with_nan_on_the_device(de
         assert bool(torch.isfinite(mu).all()) == ok and bool(torch.isfinite(var).all()) == ok
         if not ok:
             assert bool(torch.isnan(mu).all()) and bool(torch.isnan(var).all())
+
+
+def test_posterior_keeps_botorch_batch_dimensions(fitted):
+    """scamlgp/model.py:359-384 keeps x[..., m, D]'s batch dimensions; botorch's optimize_acqf sends (b, 1, D) to analytic
+    acquisition functions and (b, q, D) to joint ones.  (b, q, D) must be b independent q-point joints, NOT one joint over b q
+    points; (M, D) stays this package's flat list of M points."""
+    meta, d, gps = fitted
+    stack = gps["task0"]._stack
+    g = torch.Generator().manual_seed(15)
+    Xt = torch.rand(5, 2, dtype=torch.float64, generator=g)
+    yt = torch.tensor(synthetic.branin(-5 + 15 * Xt[:, 0].numpy(), 15 * Xt[:, 1].numpy()), dtype=torch.float64).unsqueeze(-1)
+    model = M.ScaMLGP(Xt, yt, gps).eval()
+    w = torch.tensor([0.4, 0.05, 0.3, 0.6], dtype=torch.float64)
+    model.weights = w
+    b, q = 4, 3
+    Xb = torch.rand(b, q, 2, dtype=torch.float64, generator=g)
+    post = model.posterior(Xb)
+    assert post.mean.shape == (b, q, 1) and post.variance.shape == (b, q, 1)
+    assert post.mvn.mean.shape == (b, q) and post.mvn.covariance_matrix.shape == (b, q, q)
+    theta_t = model.theta.cpu()
+    for i in range(b):   # each batch element against the oracle's joint posterior at ITS q points
+        mu_j, cov_j = _oracle_prior(stack, range(4), w, torch.cat([Xt, Xb[i]]))
+        mu_ref, S_ref = O.target_posterior(Xb[i], Xt, yt.squeeze(-1), mu_j, cov_j, theta_t, O.KIND_RBF, float(model.m_all), float(model.s_all))
+        torch.testing.assert_close(post.mvn.mean[i].cpu(), mu_ref, rtol=1e-4, atol=1e-4 * float(mu_ref.abs().max()))
+        torch.testing.assert_close(post.mvn.covariance_matrix[i].cpu(), S_ref, rtol=1e-4, atol=1e-4 * float(S_ref.abs().max()))
+        torch.testing.assert_close(post.variance[i, :, 0].cpu(), S_ref.diagonal(), rtol=1e-4, atol=1e-4 * float(S_ref.abs().max()))
+    # q = 1: shapes of botorch's analytic-acquisition call, values of the flat call
+    X1 = Xb[:, :1]
+    p1, pf = model.posterior(X1), model.posterior(X1.reshape(b, 2))
+    assert p1.mean.shape == (b, 1, 1) and p1.mvn.covariance_matrix.shape == (b, 1, 1)
+    torch.testing.assert_close(p1.mean.reshape(-1), pf.mean.reshape(-1), rtol=0, atol=0)
+    ucb = utils.UpperConfidenceBound(model)
+    assert ucb(X1).shape == (b,) and torch.equal(ucb(X1), ucb(X1.reshape(b, 2)))
+    assert utils.ExpectedImprovement(model, 0.0)(X1).shape == (b,)
+    with pytest.raises(ValueError, match="q = 1"):
+        ucb(Xb)
+    # eval-mode forward: the prior of each batch element's q points
+    fw = model.forward(Xb)
+    assert fw.mean.shape == (b, q) and fw.covariance_matrix.shape == (b, q, q)
+    f0 = model.forward(Xb[2])
+    torch.testing.assert_close(fw.mean[2], f0.mean, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(fw.covariance_matrix[2], f0.covariance_matrix, rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):
+        gps["task0"].posterior(Xb)
+
+
+def test_model_mll_and_grad_kernel_matches_torch_objective(fitted):
+    """ScaMLGP.mll_and_grad (ONE launch of scaml_target_mll_f64) against the torch-autograd objective ScaMLGP.mll it replaces in
+    the refit, and against the oracle."""
+    meta, d, gps = fitted
+    g = torch.Generator().manual_seed(25)
+    n = 9
+    Xt = torch.rand(n, 2, dtype=torch.float64, generator=g)
+    yt = torch.tensor(synthetic.branin(-5 + 15 * Xt[:, 0].numpy(), 15 * Xt[:, 1].numpy()), dtype=torch.float64).unsqueeze(-1)
+    model = M.ScaMLGP(Xt, yt, gps)
+    model.weights = torch.tensor([0.4, 0.05, 0.3, 0.6], dtype=torch.float64)
+    z = torch.cat([model.raw_theta, model.raw_weights]).clone().requires_grad_(True)
+    val_t = model.mll(z[:4], z[4:])
+    (g_t,) = torch.autograd.grad(val_t, z)
+    val_k, g_k = model.mll_and_grad()
+    np.testing.assert_allclose(float(val_k[0]), float(val_t), rtol=1e-9)
+    torch.testing.assert_close(g_k[0], g_t, rtol=1e-6, atol=1e-9)
+    ref = O.target_train_mll(Xt, model.train_targets.cpu(), model.source_means.cpu(), model.source_covs.cpu(), model.weights.cpu(),
+                             model.theta.cpu(), O.KIND_RBF, float(model.m_all), float(model.s_all))
+    np.testing.assert_allclose(float(val_k[0]), float(ref), rtol=1e-6)
+    # the refit through the kernel does not end below the torch / scipy refit it replaces
+    state = model.state_dict()
+    torch.manual_seed(11)
+    utils.optimize_marginal_likelihood(model, 1)
+    got = float(model.mll())
+    model.load_state_dict(state)
+    torch.manual_seed(11)
+    utils._fit_target(model, 1, use_kernel=False)
+    assert got >= float(model.mll()) - 1e-3 * max(1.0, abs(got))
