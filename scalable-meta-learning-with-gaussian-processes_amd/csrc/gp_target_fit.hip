@@ -28,7 +28,6 @@
 #include <hip/hip_runtime.h>
 #include "scaml_common.hpp"
 #define TF_DEV __device__ __forceinline__
-#define TF_DEV_CALL __device__ __noinline__   // one copy of the evaluation: the optimiser calls it from three places
 #define TF_SYNC() __syncthreads()
 #define TF_LANES 64
 #else
@@ -36,11 +35,18 @@
 #include <stddef.h>
 #include <stdint.h>
 #define TF_DEV static inline
-#define TF_DEV_CALL static
 #define TF_SYNC() ((void)0)
 #define TF_LANES 1
 #endif
 #include "gp_target_params.h"
+
+// diagnostic builds (tools/target_fit_probe.hip): phase stamps of one evaluation, 100 MHz wall clock, thread 0
+#if defined(SCAML_TF_STAMPS) && !defined(SCAML_HOST_EMUL)
+__device__ long long* g_tf_stamps;
+#define TF_STAMP(i) do { if (c.tid == 0 && g_tf_stamps) g_tf_stamps[i] = (long long)wall_clock64(); } while (0)
+#else
+#define TF_STAMP(i) ((void)0)
+#endif
 
 namespace scaml {
 
@@ -110,6 +116,20 @@ TF_DEV double tf_prior_dlogp(const TargetPrior& p, double x) {
   return 0.0;
 }
 
+// 1 / x for a pivot: f32 seed + two Newton steps (error 2^-22 -> 2^-44 -> 2^-88, then rounding) instead of the ~40-instruction
+// fp64 division, which sat on every column's critical path; outside the f32 range the plain division
+TF_DEV double tf_rcp(double x) {
+#ifndef SCAML_HOST_EMUL
+  if (x > 1e-30 && x < 1e30) {
+    double y = (double)__builtin_amdgcn_rcpf((float)x);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y);
+    return y;
+  }
+#endif
+  return 1.0 / x;
+}
+
 // k(x_a, x_b) / os and d(k / os) / d(d2) for the scaled squared distance d2 (a != b)
 TF_DEV void tf_kernel(int kind, double d2, double& kk, double& dk) {
   if (kind == 0) {
@@ -127,7 +147,7 @@ TF_DEV void tf_kernel(int kind, double d2, double& kk, double& dk) {
 // One evaluation at z (P doubles, global): returns mll (every thread) and, if gz != nullptr, d mll / d z.
 // info_out / jit_out: status of the factorisation (thread 0 writes them if given).  A matrix that is not positive definite
 // even with the largest jitter gives NaN.
-TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z, double* gz, int32_t* info_out, double* jit_out) {
+TF_DEV double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z, double* gz, int32_t* info_out, double* jit_out) {
   const int n = c.n, T = c.T, D = c.D, E = c.E;
   const TargetSpec& sp = p.spec;
   const double inv_s = 1.0 / p.s_all, inv_s2 = inv_s * inv_s;
@@ -146,6 +166,7 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
     c.w2[i] = wi * wi * inv_s2;
   }
   TF_SYNC();
+  TF_STAMP(0);
   const double os = c.theta[D], noise = c.theta[D + 1];
   int fail = 0;
   double jit = 0.0;
@@ -155,9 +176,21 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
     for (int e = c.tid; e < E; e += c.nthr) {
       int a, b;
       tf_decode(e, a, b);
-      double acc = 0.0;
+      // (eight loads in flight per trip: one exposed memory round trip per task was 37 us of a 365-us evaluation)
+      double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
       const double* cp = p.covs_p + e;
-      for (int i = 0; i < T; ++i) acc += c.w2[i] * cp[(size_t)i * E];
+      int i = 0;
+      for (; i + 8 <= T; i += 8) {
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = cp[(size_t)(i + j) * E];
+        acc += c.w2[i] * x[0] + c.w2[i + 4] * x[4];
+        acc1 += c.w2[i + 1] * x[1] + c.w2[i + 5] * x[5];
+        acc2 += c.w2[i + 2] * x[2] + c.w2[i + 6] * x[6];
+        acc3 += c.w2[i + 3] * x[3] + c.w2[i + 7] * x[7];
+      }
+      for (; i < T; ++i) acc += c.w2[i] * cp[(size_t)i * E];
+      acc = (acc + acc1) + (acc2 + acc3);
       double k = os;
       if (a != b) {
         double d2 = 0.0;
@@ -175,8 +208,16 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
       c.Tp[e] = 0.0;
     }
     for (int b = c.tid; b < n; b += c.nthr) {
-      double m = 0.0;
-      for (int i = 0; i < T; ++i) m += c.w[i] * p.means_t[(size_t)i * n + b];
+      double m = 0.0, m1 = 0.0;
+      int i = 0;
+      for (; i + 4 <= T; i += 4) {
+        const double x0 = p.means_t[(size_t)i * n + b], x1 = p.means_t[(size_t)(i + 1) * n + b], x2 = p.means_t[(size_t)(i + 2) * n + b],
+                     x3 = p.means_t[(size_t)(i + 3) * n + b];
+        m += c.w[i] * x0 + c.w[i + 2] * x2;
+        m1 += c.w[i + 1] * x1 + c.w[i + 3] * x3;
+      }
+      for (; i < T; ++i) m += c.w[i] * p.means_t[(size_t)i * n + b];
+      m += m1;
       c.Ap[tf_idxL(n, b)] = p.y[b] - (m - p.m_all) * inv_s;
     }
     if (c.tid == 0) c.Ap[tf_idxL(n, n)] = 0.0;
@@ -185,8 +226,11 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
     for (int b = c.tid; b <= n; b += c.nthr) c.col[b] = c.Ap[tf_idxL(b, 0)];
     TF_SYNC();
     // ---- elimination: column k of the (n + 1) x (n + 1) bordered matrix, rows of the identity block riding along ----
+    TF_STAMP(1);
     fail = 0;
+    int first = c.wave > 0 ? c.wave : c.nwave;
     for (int k = 0; k < n; ++k) {
+      if (first <= k) first += c.nwave;
       const double* cur = c.col + (k & 1) * (n + 1);
       double* nxt = c.col + ((k + 1) & 1) * (n + 1);
       const double pv = cur[k];
@@ -194,21 +238,51 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
         fail = k + 1;
         break;
       }
-      const double inv = 1.0 / pv;
-      for (int r = c.wave; r <= n; r += c.nwave) {
-        if (r <= k) {      // identity block: row r holds (L~^-1)^T e_r so far, columns k + 1 .. n - 1 still to go
-          const int base = tf_rowT(r, n);
-          const double f = c.Tp[base + k] * inv;
-          if (f != 0.0) {
-            for (int b = k + 1 + c.lane; b < n; b += TF_LANES) c.Tp[base + b] -= f * cur[b];
+      const double inv = tf_rcp(pv);
+      // Rows r = wave, wave + nwave, ... (cyclic: the triangle's rows get shorter), a lane per column b.  Four rows per trip: their
+      // LDS reads go out together, so a trip costs one LDS round trip instead of four (the wave executes in order; with one row
+      // per trip the step was a chain of exposed ~120-cycle latencies, 7 k cycles per column at n = 80).
+      for (int b = k + 1 + c.lane; b <= n; b += TF_LANES) {
+        const double cb = cur[b];
+        // identity block: row r <= k holds (L~^-1)^T e_r so far; columns k + 1 .. n - 1 still to go
+        if (b < n) {
+          for (int r0 = c.wave; r0 <= k; r0 += 4 * c.nwave) {
+            double f[4], v[4];
+            int ix[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int r = r0 + j * c.nwave;
+              const int base = tf_rowT(r <= k ? r : r0, n);
+              ix[j] = base + b;
+              f[j] = c.Tp[base + k];
+              v[j] = c.Tp[ix[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (r0 + j * c.nwave <= k) c.Tp[ix[j]] = v[j] - f[j] * inv * cb;
+            }
           }
-        } else {           // matrix rows (r == n: the right-hand side, whose diagonal entry collects -quad)
-          const int base = tf_idxL(r, 0);
-          const double f = cur[r] * inv;
-          for (int b = k + 1 + c.lane; b <= r; b += TF_LANES) {
-            const double v = c.Ap[base + b] - f * cur[b];
-            c.Ap[base + b] = v;
-            if (b == k + 1) nxt[r] = v;
+        }
+        // matrix rows r > k (r == n: the right-hand side, whose diagonal entry collects -quad), columns k + 1 .. r
+        for (int r0 = first; r0 <= n; r0 += 4 * c.nwave) {   // first: the first row > k of this wave's residue class
+          double f[4], v[4];
+          int ix[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j * c.nwave;
+            const int rr = r <= n ? r : r0;
+            ix[j] = tf_idxL(rr, 0) + (b <= rr ? b : rr);
+            f[j] = cur[rr];
+            v[j] = c.Ap[ix[j]];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = r0 + j * c.nwave;
+            if (r <= n && b <= r) {
+              const double u = v[j] - f[j] * inv * cb;
+              c.Ap[ix[j]] = u;
+              if (b == k + 1) nxt[r] = u;
+            }
           }
         }
       }
@@ -231,6 +305,7 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
 #endif
   }
   // ---- pivots, v = L^-1 r, quad, logdet ----
+  TF_STAMP(2);
   double ld = 0.0;
   for (int k = c.tid; k < n; k += c.nthr) {
     const double pv = c.Ap[tf_idxL(k, k)];
@@ -249,6 +324,7 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
   const double logprior = tf_block_sum(c, lp);
   const double value = (-0.5 * (quad + logdet + n * 1.8378770664093453) + logprior) / n;
   if (!gz) return value;
+  TF_STAMP(3);
   // ---- U = L^-T scaled: U[j][k] = (L^-1)[k][j], rows j, columns k >= j ----
   for (int j = c.wave; j < n; j += c.nwave) {
     const int b0 = tf_rowT(j, n);
@@ -265,29 +341,51 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
   }
   TF_SYNC();
   // G = (alpha alpha^T - K^-1) / 2, off-diagonal elements doubled (they stand for both halves), into Ap
+  TF_STAMP(4);
   for (int e = c.tid; e < E; e += c.nthr) {
     int a, b;
     tf_decode(e, a, b);
     const int ba = tf_rowT(a, n), bb = tf_rowT(b, n);
-    double s = 0.0;
-    for (int k = a; k < n; ++k) s += c.Tp[ba + k] * c.Tp[bb + k];
+    double s = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = a;
+    for (; k + 4 <= n; k += 4) {
+      const double u0 = c.Tp[ba + k], u1 = c.Tp[ba + k + 1], u2 = c.Tp[ba + k + 2], u3 = c.Tp[ba + k + 3];
+      const double w0 = c.Tp[bb + k], w1 = c.Tp[bb + k + 1], w2 = c.Tp[bb + k + 2], w3 = c.Tp[bb + k + 3];
+      s += u0 * w0;
+      s1 += u1 * w1;
+      s2 += u2 * w2;
+      s3 += u3 * w3;
+    }
+    for (; k < n; ++k) s += c.Tp[ba + k] * c.Tp[bb + k];
+    s = (s + s1) + (s2 + s3);
     const double g = 0.5 * (c.alpha[a] * c.alpha[b] - s);
     c.Ap[e] = a == b ? g : 2.0 * g;
   }
   TF_SYNC();
   const double inv_n = 1.0 / n;
+  TF_STAMP(5);
   // ---- d / d w_i: one wave per task ----
   for (int i = c.wave; i < T; i += c.nwave) {
     const double* cp = p.covs_p + (size_t)i * E;
     const double* mp = p.means_t + (size_t)i * n;
-    double acc = 0.0, accm = 0.0;
-    for (int e = c.lane; e < E; e += TF_LANES) acc += c.Ap[e] * cp[e];
+    double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0, accm = 0.0;
+    int e = c.lane;
+    for (; e + 3 * TF_LANES < E; e += 4 * TF_LANES) {   // four coalesced loads in flight per trip
+      const double x0 = cp[e], x1 = cp[e + TF_LANES], x2 = cp[e + 2 * TF_LANES], x3 = cp[e + 3 * TF_LANES];
+      acc += c.Ap[e] * x0;
+      acc1 += c.Ap[e + TF_LANES] * x1;
+      acc2 += c.Ap[e + 2 * TF_LANES] * x2;
+      acc3 += c.Ap[e + 3 * TF_LANES] * x3;
+    }
+    for (; e < E; e += TF_LANES) acc += c.Ap[e] * cp[e];
+    acc = (acc + acc1) + (acc2 + acc3);
     for (int a = c.lane; a < n; a += TF_LANES) accm += c.alpha[a] * mp[a];
     const double wi = c.w[i];
     const double tot = tf_wave_sum(acc * (2.0 * wi * inv_s2) + accm * inv_s);
     if (tf_last_lane(c)) gz[D + 2 + i] = (tot + tf_prior_dlogp(sp.w_prior, wi)) * inv_n;
   }
   // ---- d / d (lengthscales, outputscale, noise) ----
+  TF_STAMP(6);
   double gl[TARGET_FIT_DMAX];
 #pragma unroll
   for (int d = 0; d < TARGET_FIT_DMAX; ++d) gl[d] = 0.0;
@@ -344,6 +442,7 @@ TF_DEV_CALL double tf_eval(const TfCtx& c, const TargetFitParams& p, const doubl
     gz[q] = (s + tf_prior_dlogp(pr, th)) * c.dth[q] * inv_n;
   }
   TF_SYNC();
+  TF_STAMP(7);
   return value;
 }
 
@@ -356,147 +455,179 @@ TF_DEV double tf_dot(const TfCtx& c, const double* a, const double* b) {
 
 TF_DEV bool tf_finite(double x) { return x - x == 0.0; }
 
-TF_DEV void tf_lbfgs(const TfCtx& c, const TargetFitParams& p, int prob) {
+// The whole kernel body as ONE loop around ONE call of tf_eval (a state machine: the evaluation is inlined exactly once, its LDS
+// pointers stay 32-bit LDS addresses in registers; three call sites out of line made every LDS access a flat access through a
+// context struct in memory):
+//   EVAL_ONLY  mode 0: value + gradient at z, done
+//   INIT       first evaluation at the start point              -> direction, first trial point
+//   TRIAL      evaluation at a line-search trial point          -> accept (curvature pair, stopping rules, new direction) or halve the step
+//   FINAL      value (and factorisation status) at the point kept
+TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
+  enum { EVAL_ONLY = 0, INIT = 1, TRIAL = 2, FINAL = 3 };
   const int P = c.P, D = c.D, H = p.history;
-  double* ws = p.workspace + (size_t)prob * (6 + 2 * H) * P;
-  double *x = p.z + (size_t)prob * P, *g = ws, *xn = ws + P, *gn = ws + 2 * P, *dvec = ws + 3 * P, *q = ws + 4 * P, *mask = ws + 5 * P;
+  int32_t* info_out = p.info ? p.info + prob : nullptr;
+  double* jit_out = p.jitter ? p.jitter + prob : nullptr;
+  double* x = p.z + (size_t)prob * P;
+  double* ws = p.mode == 0 ? nullptr : p.workspace + (size_t)prob * (6 + 2 * H) * P;
+  double *g = ws, *xn = ws + P, *gn = ws + 2 * P, *dvec = ws + 3 * P, *q = ws + 4 * P, *mask = ws + 5 * P;
   double* S = ws + 6 * P;
   double* Y = S + (size_t)H * P;
   double* rho = c.sc + 8;                       // [H]
   double* al = c.sc + 8 + TARGET_FIT_HMAX;      // [H]
   const double lb = p.spec.w_lower;
   const double c1 = 1e-4;
-  // start inside the box
-  for (int i = D + 2 + c.tid; i < P; i += c.nthr) x[i] = fmax(x[i], lb);
-  TF_SYNC();
-  int32_t* info_out = p.info ? p.info + prob : nullptr;
-  double* jit_out = p.jitter ? p.jitter + prob : nullptr;
-  double f = -tf_eval(c, p, x, g, info_out, jit_out);
-  for (int i = c.tid; i < P; i += c.nthr) g[i] = -g[i];
-  TF_SYNC();
-  int n_eval = 1, it = 0, status = 0, hist = 0, head = 0;   // status 0 running/maxiter, 1 converged (gradient), 2 converged (decrease), 3 line search failed, 4 bad start
-  if (!tf_finite(f)) status = 4;
-  while (status == 0 && it < p.max_iter) {
-    ++it;
-    // free variables: everything except weights sitting on the bound whose gradient pushes outwards
-    for (int i = c.tid; i < P; i += c.nthr) {
-      const bool fixed = i >= D + 2 && x[i] <= lb && g[i] > 0.0;
-      mask[i] = fixed ? 0.0 : 1.0;
-      q[i] = fixed ? 0.0 : g[i];
-    }
+  int state = p.mode == 0 ? EVAL_ONLY : INIT;
+  const double* zc = x;
+  double* gout = p.mode == 0 ? p.grad + (size_t)prob * P : g;
+  if (state == INIT) {   // start inside the box
+    for (int i = D + 2 + c.tid; i < P; i += c.nthr) x[i] = fmax(x[i], lb);
     TF_SYNC();
-    // two-loop recursion, newest pair first (pair h lives in slot (head - 1 - h) mod H)
-    for (int h = 0; h < hist; ++h) {
-      const int slot = (head - 1 - h + 2 * H) % H;
-      const double a = rho[slot] * tf_dot(c, S + (size_t)slot * P, q);
-      if (c.tid == 0) al[slot] = a;
-      for (int i = c.tid; i < P; i += c.nthr) q[i] -= a * Y[(size_t)slot * P + i];
-      TF_SYNC();
-    }
-    double gamma = 1.0;
-    if (hist > 0) {
-      const int slot = (head - 1 + H) % H;
-      const double yy = tf_dot(c, Y + (size_t)slot * P, Y + (size_t)slot * P);
-      if (yy > 0.0) gamma = 1.0 / (rho[slot] * yy);
-    }
-    for (int i = c.tid; i < P; i += c.nthr) q[i] *= gamma;
-    TF_SYNC();
-    for (int h = hist - 1; h >= 0; --h) {
-      const int slot = (head - 1 - h + 2 * H) % H;
-      const double b = rho[slot] * tf_dot(c, Y + (size_t)slot * P, q);
-      const double a = al[slot];
-      for (int i = c.tid; i < P; i += c.nthr) q[i] += (a - b) * S[(size_t)slot * P + i];
-      TF_SYNC();
-    }
-    for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -q[i] * mask[i];
-    TF_SYNC();
-    double gd = tf_dot(c, g, dvec);
-    double t = 1.0;
-    if (!(gd < 0.0) || hist == 0) {   // first step / not a descent direction: steepest descent, scipy-like first step length
-      for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -g[i] * mask[i];
-      TF_SYNC();
-      gd = tf_dot(c, g, dvec);
-      const double gn2 = -gd;
-      t = fmin(1.0, 1.0 / sqrt(fmax(gn2, 1e-24)));
-      if (!(gd < 0.0)) {   // projected gradient is zero: converged
-        status = 1;
-        break;
+  }
+  double f = 0.0, t = 1.0, gd = 0.0;
+  int n_eval = 0, it = 0, status = 0, hist = 0, head = 0, ls = 0;   // status 0 max_iter, 1 converged (gradient), 2 converged (decrease), 3 line search failed, 4 bad start
+  for (;;) {
+    const bool report = state != TRIAL;
+    const double val = tf_eval(c, p, zc, gout, report ? info_out : nullptr, report ? jit_out : nullptr);
+    ++n_eval;
+    if (state == EVAL_ONLY || state == FINAL) {
+      if (c.tid == 0) {
+        p.value[prob] = val;
+        if (state == FINAL && p.stats) {
+          p.stats[4 * prob + 0] = it;
+          p.stats[4 * prob + 1] = n_eval;
+          p.stats[4 * prob + 2] = status;
+          p.stats[4 * prob + 3] = 0;
+        }
       }
+      return;
     }
-    // projected backtracking line search
-    bool accepted = false;
-    double fn = f;
-    for (int ls = 0; ls < p.max_ls; ++ls) {
-      for (int i = c.tid; i < P; i += c.nthr) {
-        double v = x[i] + t * dvec[i];
-        if (i >= D + 2) v = fmax(v, lb);
-        xn[i] = v;
-      }
+    bool go_final = false, new_dir = false;
+    if (state == INIT) {
+      f = -val;
+      for (int i = c.tid; i < P; i += c.nthr) g[i] = -g[i];
       TF_SYNC();
-      fn = -tf_eval(c, p, xn, gn, nullptr, nullptr);
-      ++n_eval;
+      if (!tf_finite(f)) {
+        status = 4;
+        go_final = true;
+      } else if (p.max_iter < 1) {
+        go_final = true;
+      } else {
+        new_dir = true;
+      }
+    } else {   // TRIAL: xn, gn hold the trial point and +d mll / dz there
+      const double fn = -val;
       double dec = 0.0;
       for (int i = c.tid; i < P; i += c.nthr) dec += g[i] * (xn[i] - x[i]);
       dec = tf_block_sum(c, dec);
       if (tf_finite(fn) && fn <= f + c1 * dec) {
-        accepted = true;
-        break;
+        // curvature pair, then the step
+        double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
+        const int slot = head;
+        for (int i = c.tid; i < P; i += c.nthr) {
+          const double gi = -gn[i];
+          const double sv = xn[i] - x[i], yv = gi - g[i];
+          sy += sv * yv;
+          ss += sv * sv;
+          yy += yv * yv;
+        }
+        sy = tf_block_sum(c, sy);
+        ss = tf_block_sum(c, ss);
+        yy = tf_block_sum(c, yy);
+        const bool push = sy > 1e-10 * sqrt(ss) * sqrt(yy);
+        for (int i = c.tid; i < P; i += c.nthr) {
+          const double gi = -gn[i];
+          if (push) {
+            S[(size_t)slot * P + i] = xn[i] - x[i];
+            Y[(size_t)slot * P + i] = gi - g[i];
+          }
+          x[i] = xn[i];
+          g[i] = gi;
+          // projected gradient (scipy's pgtol test): |P(x - g) - x|
+          double st = x[i] - gi;
+          if (i >= D + 2) st = fmax(st, lb);
+          pg = fmax(pg, fabs(st - x[i]));
+        }
+        if (push) {
+          if (c.tid == 0) rho[slot] = 1.0 / sy;
+          head = (head + 1) % H;
+          if (hist < H) ++hist;
+        }
+        pg = tf_block_max(c, pg);
+        const double rel = (f - fn) / fmax(fmax(fabs(f), fabs(fn)), 1.0);
+        f = fn;
+        if (pg <= p.gtol) { status = 1; go_final = true; }
+        else if (rel <= p.ftol && it > 1) { status = 2; go_final = true; }
+        else if (it >= p.max_iter) { go_final = true; }
+        else new_dir = true;
+      } else {
+        t *= 0.5;
+        if (++ls >= p.max_ls) { status = 3; go_final = true; }
       }
-      t *= 0.5;
     }
-    if (!accepted) {
-      status = 3;
-      break;
-    }
-    // curvature pair (gn holds +d mll/dz: negate on the fly)
-    double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
-    const int slot = head;
-    for (int i = c.tid; i < P; i += c.nthr) {
-      const double gi = -gn[i];
-      const double s = xn[i] - x[i], y = gi - g[i];
-      sy += s * y;
-      ss += s * s;
-      yy += y * y;
-      q[i] = gi;   // (q is free again: new gradient staged here)
-    }
-    sy = tf_block_sum(c, sy);
-    ss = tf_block_sum(c, ss);
-    yy = tf_block_sum(c, yy);
-    const bool push = sy > 1e-10 * sqrt(ss) * sqrt(yy);
-    for (int i = c.tid; i < P; i += c.nthr) {
-      const double gi = q[i];
-      if (push) {
-        S[(size_t)slot * P + i] = xn[i] - x[i];
-        Y[(size_t)slot * P + i] = gi - g[i];
+    if (new_dir) {
+      ++it;
+      ls = 0;
+      // free variables: everything except weights sitting on the bound whose gradient pushes outwards
+      for (int i = c.tid; i < P; i += c.nthr) {
+        const bool fixed = i >= D + 2 && x[i] <= lb && g[i] > 0.0;
+        mask[i] = fixed ? 0.0 : 1.0;
+        q[i] = fixed ? 0.0 : g[i];
       }
-      x[i] = xn[i];
-      g[i] = gi;
-      // projected gradient (scipy's pgtol test): |P(x - g) - x|
-      double st = x[i] - gi;
-      if (i >= D + 2) st = fmax(st, lb);
-      pg = fmax(pg, fabs(st - x[i]));
+      TF_SYNC();
+      // two-loop recursion, newest pair first (pair h lives in slot (head - 1 - h) mod H)
+      for (int h = 0; h < hist; ++h) {
+        const int slot = (head - 1 - h + 2 * H) % H;
+        const double a = rho[slot] * tf_dot(c, S + (size_t)slot * P, q);
+        if (c.tid == 0) al[slot] = a;
+        for (int i = c.tid; i < P; i += c.nthr) q[i] -= a * Y[(size_t)slot * P + i];
+        TF_SYNC();
+      }
+      double gamma = 1.0;
+      if (hist > 0) {
+        const int slot = (head - 1 + H) % H;
+        const double yy = tf_dot(c, Y + (size_t)slot * P, Y + (size_t)slot * P);
+        if (yy > 0.0) gamma = 1.0 / (rho[slot] * yy);
+      }
+      for (int i = c.tid; i < P; i += c.nthr) q[i] *= gamma;
+      TF_SYNC();
+      for (int h = hist - 1; h >= 0; --h) {
+        const int slot = (head - 1 - h + 2 * H) % H;
+        const double b = rho[slot] * tf_dot(c, Y + (size_t)slot * P, q);
+        const double a = al[slot];
+        for (int i = c.tid; i < P; i += c.nthr) q[i] += (a - b) * S[(size_t)slot * P + i];
+        TF_SYNC();
+      }
+      for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -q[i] * mask[i];
+      TF_SYNC();
+      gd = tf_dot(c, g, dvec);
+      t = 1.0;
+      if (!(gd < 0.0) || hist == 0) {   // first step / not a descent direction: steepest descent, scipy-like first step length
+        for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -g[i] * mask[i];
+        TF_SYNC();
+        gd = tf_dot(c, g, dvec);
+        t = fmin(1.0, 1.0 / sqrt(fmax(-gd, 1e-24)));
+        if (!(gd < 0.0)) {   // the projected gradient is zero: converged
+          status = 1;
+          go_final = true;
+        }
+      }
     }
-    if (push) {
-      if (c.tid == 0) rho[slot] = 1.0 / sy;
-      head = (head + 1) % H;
-      if (hist < H) ++hist;
+    if (go_final) {
+      state = FINAL;
+      zc = x;
+      gout = nullptr;
+      continue;
     }
-    pg = tf_block_max(c, pg);
-    const double rel = (f - fn) / fmax(fmax(fabs(f), fabs(fn)), 1.0);
-    f = fn;
-    if (pg <= p.gtol) status = 1;
-    else if (rel <= p.ftol && it > 1) status = 2;
-  }
-  // the objective (and its status) at the point that is kept
-  const double val = tf_eval(c, p, x, nullptr, info_out, jit_out);
-  if (c.tid == 0) {
-    p.value[prob] = val;
-    if (p.stats) {
-      p.stats[4 * prob + 0] = it;
-      p.stats[4 * prob + 1] = n_eval + 1;
-      p.stats[4 * prob + 2] = status;
-      p.stats[4 * prob + 3] = 0;
+    // next trial point on the projected ray
+    for (int i = c.tid; i < P; i += c.nthr) {
+      double v = x[i] + t * dvec[i];
+      if (i >= D + 2) v = fmax(v, lb);
+      xn[i] = v;
     }
+    TF_SYNC();
+    state = TRIAL;
+    zc = xn;
+    gout = gn;
   }
 }
 
@@ -523,22 +654,20 @@ TF_DEV void tf_carve(TfCtx& c, double* lds, int n, int T, int D, int nwave) {
 TF_DEV void tf_main(TfCtx& c, const TargetFitParams& p, int prob) {
   for (int i = c.tid; i < c.n * c.D; i += c.nthr) c.Xs[i] = p.X[i];
   TF_SYNC();
-  if (p.mode == 0) {
-    const double v = tf_eval(c, p, p.z + (size_t)prob * c.P, p.grad + (size_t)prob * c.P, p.info + prob, p.jitter ? p.jitter + prob : nullptr);
-    if (c.tid == 0) p.value[prob] = v;
-  } else {
-    tf_lbfgs(c, p, prob);
-  }
+  tf_run(c, p, prob);
 }
 
 #ifndef SCAML_HOST_EMUL
-extern "C" __global__ __launch_bounds__(512) void scaml_target_fit_kernel(TargetFitParams p) {
+#ifndef TF_MAX_THREADS
+#define TF_MAX_THREADS 512
+#endif
+extern "C" __global__ __launch_bounds__(TF_MAX_THREADS) void scaml_target_fit_kernel(TargetFitParams p) {
   extern __shared__ double tf_lds[];
   TfCtx c;
   c.tid = threadIdx.x;
   c.nthr = blockDim.x;
   c.lane = threadIdx.x & 63;
-  c.wave = threadIdx.x >> 6;
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: every row index derived from it is SALU work, off the vector unit)
   c.nwave = blockDim.x >> 6;
   c.n = p.n; c.T = p.T; c.D = p.D; c.P = p.D + 2 + p.T; c.E = p.n * (p.n + 1) / 2; c.kind = p.kind;
   tf_carve(c, tf_lds, p.n, p.T, p.D, c.nwave);

@@ -131,6 +131,67 @@ def test_config4_bo_loop_hartmann6_ei_matches_oracle(device):
     assert bool((loop.model.weights >= 1e-10).all())
 
 
+def test_config4_full_stack_scoring_pass(device):
+    """BASELINE configs[4] at its full stack: T = 32 source tasks x N = 512 points x D = 6, Matern-5/2 -- blocked fit, explicit
+    L^-1, fused-covariance posteriors at 80 target points + candidates, weighted sums, the target GP's four launches, EI.  Properties
+    on every task (L L^T = K + noise I, K alpha = y, L^-1 L = I), the oracle on three sampled tasks, the oracle's target posterior and
+    EI on the candidates (1e-4).  (The jitter ladder at this stack size is exercised at ops level, test_blocked_fit_gpu.py::
+    test_blocked_fit_full_stack_task_groups: constrained hyper-parameters keep the noise >= 1e-8, which never needs it in fp64.)"""
+    T, N, D, n, Mq = 32, 512, 6, 80, 96
+    kind = O.KIND_MATERN52
+    d = synthetic.hartmann6_task_stack(T, N, seed=3, noise_std=0.1)
+    stack = M.SourceGPStack([f"h{t}" for t in range(T)], [torch.from_numpy(d["X"][t]) for t in range(T)],
+                            [torch.from_numpy(d["Y"][t]).unsqueeze(-1) for t in range(T)], kind=kind, device=device)
+    rng = np.random.default_rng(4)
+    theta = torch.from_numpy(np.concatenate([0.6 + 0.8 * rng.uniform(size=(T, D)), 0.5 + rng.uniform(size=(T, 1)),
+                                             1e-3 + 5e-3 * rng.uniform(size=(T, 1))], 1))
+    stack.set_theta(theta)
+    fit = stack.refresh()
+    gps = {tid: M.SourceGP(stack, i) for i, tid in enumerate(stack.task_ids)}
+    # -- every task, on the device
+    K = ops.kernel_matrix(stack.X, stack.theta, kind, add_noise=True)
+    L = torch.tril(fit["L"])
+    eye = torch.eye(N, dtype=torch.float64, device=device)
+    for t in range(T):
+        assert float((L[t] @ L[t].T - K[t]).abs().max()) <= 1e-11 * float(K[t].abs().max())
+        assert float((K[t] @ fit["alpha"][t] - stack.y[t]).abs().max()) <= 1e-7 * float(stack.y[t].abs().max())
+        assert float((fit["Linv"][t] @ L[t] - eye).abs().max()) <= 1e-8
+    del K
+    # -- three tasks against the oracle
+    for t in (0, 13, 31):
+        ref = O.gp_fit(stack.X[t].cpu(), stack.y[t].cpu(), stack.theta[t].cpu(), kind)
+        torch.testing.assert_close(L[t].cpu(), ref["L"], rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(fit["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-4 * float(ref["alpha"].abs().max()))
+        np.testing.assert_allclose(float(fit["mll"][t]), float(ref["mll"]), rtol=1e-3)
+    # -- the scoring pass of one BO step: 80 target points, EI on the candidates
+    g = torch.Generator().manual_seed(6)
+    Xt = torch.rand(n, D, dtype=torch.float64, generator=g)
+    yt = torch.from_numpy(synthetic.hartmann6(Xt.numpy(), alpha=np.array([1.01, 1.19, 2.9, 3.3]))).unsqueeze(-1)
+    model = M.ScaMLGP(Xt, yt, gps).eval()
+    w = torch.from_numpy(0.01 + 0.1 * rng.uniform(size=T))
+    w[5] = 1e-9                                      # one pruned task
+    model.weights = w
+    cand = torch.rand(Mq, D, dtype=torch.float64, generator=g)
+    best_f = float(yt.min())
+    post = model.posterior(cand)
+    ei = utils.ExpectedImprovement(model, best_f)(cand).cpu()
+    fits = [O.gp_fit(stack.X[t].cpu(), stack.y[t].cpu(), stack.theta[t].cpu(), kind) for t in range(T)]
+    mu_ref, S_ref = _oracle_target_posterior(model, fits, cand)
+    var_ref = S_ref.diagonal()
+    torch.testing.assert_close(post.mvn.mean.cpu(), mu_ref, rtol=1e-4, atol=1e-4 * float(mu_ref.abs().max()))
+    torch.testing.assert_close(post.mvn.variance.cpu(), var_ref, rtol=1e-4, atol=1e-4 * float(var_ref.abs().max()))
+    ei_ref = O.expected_improvement_minimize(mu_ref, var_ref, best_f)
+    torch.testing.assert_close(ei, ei_ref, rtol=1e-4, atol=1e-4 * float(ei_ref.abs().max()) + 1e-300)
+    # -- the same pass at the acquisition optimiser's raw batch (1024 candidates): consistent with the small batch, finite, EI >= 0
+    big = torch.cat([cand, torch.rand(1024 - Mq, D, dtype=torch.float64, generator=g)])
+    pb = model.posterior(big)
+    torch.testing.assert_close(pb.mvn.mean[:Mq], post.mvn.mean, rtol=1e-9, atol=1e-12)
+    torch.testing.assert_close(pb.mvn.variance[:Mq], post.mvn.variance, rtol=1e-7, atol=1e-12)
+    eb = utils.ExpectedImprovement(model, best_f)(big)
+    # (sigma (phi(u) + u Phi(u)) cancels for u << 0 and may round to a tiny negative number: botorch's formula, not a kernel property)
+    assert bool(torch.isfinite(eb).all()) and float(eb.min()) > -1e-15 and bool((pb.mvn.variance > 0).all())
+
+
 def test_optimize_acqf_multistart_finds_known_maximum(device):
     """The acquisition optimiser on a function with a known maximiser inside the cube and a decoy at a corner."""
     target = torch.tensor([0.3, 0.7, 0.55], dtype=torch.float64)

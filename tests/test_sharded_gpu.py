@@ -97,3 +97,58 @@ def test_sharded_model_matches_single_process(device, tmp_path):
         # configs[3]'s exchange step: [sum MLL || sum dMLL/dtheta] over all ranks' tasks
         np.testing.assert_allclose(g["s_mll"], ref["s_mll"], rtol=1e-11)
         np.testing.assert_allclose(g["s_grad"], ref["s_grad"], rtol=1e-9, atol=1e-12)
+
+
+# ---- the target refit on a sharded model: every rank must end with the SAME weights and hyper-parameters -------------------
+T5 = 5   # odd: the shards differ in size (3 + 2), so the ranks' generators have consumed different amounts by the time of the refit
+
+
+def _run_target_refit(shard: bool):
+    from scamlgp_amd import model as M, synthetic, utils
+
+    d = synthetic.branin_task_stack(T5, N, seed=23, noise_std=1.0)
+    meta = {f"t{t}": M.SupervisedDataset(torch.from_numpy(d["X"][t]), torch.from_numpy(d["Y"][t]).unsqueeze(-1)) for t in range(T5)}
+    g = torch.Generator().manual_seed(18)
+    Xt = torch.rand(8, D, dtype=torch.float64, generator=g)
+    yt = torch.tensor(synthetic.branin(-5 + 15 * Xt[:, 0].numpy(), 15 * Xt[:, 1].numpy(), a=0.9, r=5.5), dtype=torch.float64).unsqueeze(-1)
+    xq = torch.rand(MQ, D, dtype=torch.float64, generator=g)
+    gps = M.meta_fit_scamlgp(meta, num_restarts_log_likelihood=1, seed=3, shard=shard)   # (restarts: the fit draws from the RNG)
+    model = M.ScaMLGP(Xt, yt, gps)
+    utils.optimize_marginal_likelihood(model, num_restarts=2)
+    post = model.eval().posterior(xq)
+    return dict(weights=model.weights.cpu().numpy(), raw_theta=model.raw_theta.cpu().numpy(), mll=float(model.mll()),
+                mean=post.mvn.mean.cpu().numpy(), var=post.mvn.variance.cpu().numpy())
+
+
+def _refit_worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "scalable-meta-learning-with-gaussian-processes_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = _run_target_refit(shard=True)
+    np.savez(os.path.join(out_dir, f"refit{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_target_refit_is_identical_on_every_rank(device, tmp_path):
+    """optimize_marginal_likelihood on a ScaMLGP over sharded sources: rank 0 fits (restart points from ITS generator), the result
+    is broadcast; weights and theta are bit-identical on all ranks, so the weighted sums they all-reduce afterwards are consistent
+    and the ranks make the same number of collective calls."""
+    world = 2
+    mp.spawn(_refit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = (dict(np.load(str(tmp_path / f"refit{r}.npz"))) for r in range(world))
+    assert np.array_equal(a["weights"], b["weights"]) and np.array_equal(a["raw_theta"], b["raw_theta"])
+    assert a["weights"].shape == (T5,) and (a["weights"] >= 1e-10).all()
+    np.testing.assert_allclose(a["mean"], b["mean"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a["var"], b["var"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a["mll"], b["mll"], rtol=1e-12)
+    assert np.isfinite(a["mll"])

@@ -12,6 +12,8 @@ import pytest
 import scipy.optimize
 import torch
 
+torch.set_num_threads(1)   # (many small oracle ops: threads only get in each other's way)
+
 from tests._target_problem import TARGET_SPEC, make_target_problem, oracle_mll_and_grad, pack_lower, raw_start
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -15,7 +15,7 @@ gps = {tid: M.SourceGP(st, i) for i, tid in enumerate(st.task_ids)}
 obj = lambda x: float(synthetic.hartmann6(np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
 loop = ScaMLGPBOLoop(gps, dim=6, acquisition="ei", num_restarts_log_likelihood=2, seed=0)
 g = torch.Generator().manual_seed(1)
-for i in range(20):   # 20 points of history
+for i in range(int(os.environ.get("BO_HISTORY", "79"))):   # points of history (configs[4]: the refit at n = 80)
     x = torch.rand(6, dtype=torch.float64, generator=g)
     loop.X = x.unsqueeze(0) if loop.X is None or len(loop.X) == 0 else torch.cat([loop.X, x.unsqueeze(0)])
     loop.Y = torch.tensor([[obj(x)]], dtype=torch.float64) if loop.Y is None or len(loop.Y) == 0 else torch.cat([loop.Y, torch.tensor([[obj(x)]], dtype=torch.float64)])
