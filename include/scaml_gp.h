@@ -248,6 +248,30 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
                             void* stream);
 
 /*
+ * (5d) Input gradients of the posterior -- what botorch's optimize_acqf differentiates through model.posterior for when it
+ * maximises the acquisition function (the caller behind scamlgp/utils.py:215-224; SURVEY 3.3, HOT LOOP #4; the reference gets
+ * them from torch autograd through kernel, solves and PsdSum per L-BFGS-B iteration).
+ * scaml_posterior_linv_grad_f64: the (5c') pass with 16 output columns per query point x_q = [value, d/dx_0 .. d/dx_{D-1}, 0 ..]:
+ *   mu  (T, Mq, 16): mu[t][q][0] = posterior mean of source t at x_q,   mu[t][q][1 + d]  = d mean / d x_d
+ *   var (T, Mq, 16): var[t][q][0] = posterior variance,                 var[t][q][1 + d] = d variance / d x_d
+ *   cov (T, Ma, Mq * 16): cov[t][a][16 q] = Cov(f(xa_a), f(x_q)),       cov[t][a][16 q + 1 + d] = d Cov / d x_d
+ * (un-standardised with y_mean / y_std as in (5)), Xq (Mq, D) the query points, Xa (Ma, D) the Ma leading points (the target's
+ * training inputs) and VA (T, N, Ma) their V as in (5c').  Ma = 0: no covariance block (VA, Xa, cov may be NULL).  D <= 15, Ma <= 96.
+ * scaml_target_posterior_grad_f64: d mu* / d x (Mq, D) and d var* / d x (Mq, D) of the ScaML-GP TARGET posterior (original units;
+ * scamlgp/model.py:359-384 eval branch + gpytorch's exact prediction) from the weighted task sums of those outputs
+ * (cov_g (n, Mq * 16), mu_g / var_g (Mq * 16): (6') applied to cov / mu / var above), the target inputs Xt (n, D), the target
+ * kernel theta (D + 2), and alpha (n), Z (n, Mq) = Knn^-1 Knq of the value path ((7): the POTRF's alpha, the Cholesky solve's result).
+ * info (1) int32 or NULL: a failed target factorisation turns the outputs into NaN.
+ */
+int scaml_posterior_linv_grad_f64(const double* Xq, const double* Xa, const double* X, const double* theta, const double* Linv,
+                                  const double* alpha, const double* y_mean, const double* y_std, const int32_t* n_points,
+                                  const double* VA, int T, int N, int Mq, int Ma, int D, int kind, double* mu, double* var, double* cov,
+                                  unsigned flags, void* stream);
+int scaml_target_posterior_grad_f64(const double* cov_g, const double* mu_g, const double* var_g, const double* Xt, const double* Xq,
+                                    const double* theta, const double* alpha, const double* Z, double s_all, const int32_t* info, int n,
+                                    int Mq, int D, int kind, double* dmu, double* dvar, void* stream);
+
+/*
  * (8) The target GP's training objective with its analytic gradient, and the whole refit, in ONE launch.
  * Replaces what the reference runs on every report(): scamlgp/optimizer.py:176-185 rebuilds ScaMLGP and calls
  * optimize_marginal_likelihood (scamlgp/utils.py:139-212), which drives scipy L-BFGS-B through torch autograd over

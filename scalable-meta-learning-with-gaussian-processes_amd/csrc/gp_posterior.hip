@@ -135,7 +135,15 @@ __global__ __launch_bounds__(256) void gp_posterior_kernel(PosteriorParams p) {
 // ahead).  LDS is 37-53 KB per workgroup, so three to four of them share a CU and hide each other's
 // latencies -- the substitution kernel above holds a 32 KB strip per WAVE and runs one wave per SIMD.
 // XCD-aware block map (see gp_mll_grad_kernel): the strips of one task share an L2.
-template <int KIND, bool COV>
+// GRAD (round 3): the same pass with the INPUT GRADIENT of the posterior.  A strip's 16 columns then belong to ONE query point x:
+// column 0 is k_*(x) as before, columns 1 .. D are d k_*(x) / d x_d (columns past D are zero), so that V = L^-1 [k_*, dk_*/dx]
+// comes out of the same triangular product and, with it,
+//   mu[.., 0] = m + s k_* . alpha,       mu[.., 1 + d]  = s (dk_*/dx_d) . alpha                    = d mu / d x_d
+//   var[.., 0] = s^2 (os - V_0 . V_0),   var[.., 1 + d] = -2 s^2 V_0 . V_{1+d}                      = d var / d x_d
+//   cov[a][.., 0] = s^2 (os k(x_a, x) - VA_a . V_0),  cov[a][.., 1 + d] = s^2 (os dk(x_a, x)/dx_d - VA_a . V_{1+d})
+// for the Ma leading points x_a (p.Xa: the target's training inputs) -- everything botorch's optimize_acqf differentiates through
+// model.posterior for (HOT LOOP #4; scamlgp/utils.py:215-224).  Outputs are (T, Mq, 16) / (T, Ma, Mq * 16): M = 16 Mq.
+template <int KIND, bool COV, bool GRAD>
 __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams p) {
   // eight waves share one K_*^T strip (the row blocks are dealt 8 ways: twice the waves per byte of LDS to hide the L^-1 segment loads)
   constexpr int NW = 8;
@@ -188,10 +196,11 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
     nr[r] = nrm;
   }
   if (tid < 16) {
-    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
+    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * (GRAD ? M / 16 : M) * D : 0);
+    const int qpoint = GRAD ? strip : qc;   // GRAD: all 16 columns of the strip are the same point
     double nrm = 0.0;
     for (int d = 0; d < D4; ++d) {
-      const double v = (qc < M && d < D) ? Xqg[(size_t)qc * D + d] * invl[d] : 0.0;
+      const double v = (qc < M && d < D) ? Xqg[(size_t)qpoint * D + d] * invl[d] : 0.0;
       xqs[d * 16 + lc] = v;
       nrm = __builtin_fma(v, v, nrm);
     }
@@ -221,7 +230,25 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
       d2v = __builtin_amdgcn_mfma_f64_16x16x4f64(lq == 0 ? nr[arow] : (lq == 1 ? 1.0 : 0.0), bn, d2v, 0, 0, 0);
       asm volatile("s_nop 15\n\ts_nop 2" : "+v"(d2v));   // (gfx950: the last result pair is not interlocked for VALU reads)
       const int row0 = 16 * kb + lq;
-      if (16 * kb + 16 <= n) {
+      if (GRAD) {
+        // column 0: the kernel value; column c = 1 + d: os dk/d(d2) * 2 (x'_d - a'_d) / l_d with primes = coordinates / l_d
+        const int dcol = lc - 1;
+        const double xqd = (dcol >= 0 && dcol < D) ? xqs[dcol * 16] : 0.0, ild = (dcol >= 0 && dcol < D) ? invl[dcol] : 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + 4 * g;
+          double kv, dk;
+          kernel_and_slope_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, exptab, kv, dk);
+          double val = kv;
+          if (lc > 0) {
+            const double xad = (row < n && dcol < D) ? Xg[(size_t)row * D + dcol] * ild : 0.0;
+            val = dcol < D ? 2.0 * dk * (xqd - xad) * ild : 0.0;
+          }
+          val = row < n ? val : 0.0;
+          Ks[(16 * kb + strip_row(lq, g)) * 16 + lc] = val;
+          mean_part = __builtin_fma(val, alpha_s[row], mean_part);
+        }
+      } else if (16 * kb + 16 <= n) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const double kv = kernel_from_sqdist_scaled<KIND>(KIND == 0 ? vmax_f64(d2v[g], 0.0) : d2v[g], kc0, kc1, kc2, exptab);
@@ -267,9 +294,11 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
       acc = block_row_accumulate_deep<false>(acc, Lrow, arow < N, 16 * kb + 16 <= N, N, n_even, Ks, 0, kb + 1, lc, lq);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        var_part = __builtin_fma(acc[g], acc[g], var_part);
+        // GRAD: V_0 . V_c instead of V_c . V_c -- the row's column-0 value sits in the lane with lc = 0 of the same lane group
+        const double other = GRAD ? __shfl(acc[g], lane & 48) : acc[g];
+        var_part = __builtin_fma(acc[g], other, var_part);
         const int row = 16 * kb + lq + 4 * g;
-        if (p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = row < n ? acc[g] : 0.0;
+        if (!GRAD && p.V && row < N && qc < M) p.V[((size_t)task * N + row) * M + qc] = row < n ? acc[g] : 0.0;
       }
       if (nas) {
         // cov tiles: (VA^T V)[a][c] += sum over the 16 rows of this block -- A = VA[rows][16 as + lc] transposed by the
@@ -301,8 +330,13 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
     __syncthreads();
   }
   if (tid < 16 && qc < M) {
-    if (p.mu) p.mu[(size_t)task * M + qc] = __builtin_fma(ys, red[tid], ym);
-    if (p.var) p.var[(size_t)task * M + qc] = ys * ys * (os - red[16 + tid]);
+    if (GRAD && tid > 0) {
+      if (p.mu) p.mu[(size_t)task * M + qc] = ys * red[tid];
+      if (p.var) p.var[(size_t)task * M + qc] = -2.0 * ys * ys * red[16 + tid];
+    } else {
+      if (p.mu) p.mu[(size_t)task * M + qc] = __builtin_fma(ys, red[tid], ym);
+      if (p.var) p.var[(size_t)task * M + qc] = ys * ys * (os - red[16 + tid]);
+    }
   }
   if (nas && !p.mean_only) {
     // the four waves' partial tiles are added in a fixed order in the (now free) K_*^T strip, then
@@ -327,7 +361,8 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
       }
       __syncthreads();
     }
-    const double* Xqg = p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
+    // the Ma leading points: the head of the query list (the caller put the target's training points first), or p.Xa
+    const double* Xqg = p.Xa ? p.Xa : p.Xq + (p.xq_per_task ? (size_t)task * M * D : 0);
     for (int e = tid; e < nas * 256; e += blockDim.x) {
       const int as = e >> 8, g = (e >> 6) & 3, ln = e & 63;
       const int a = 16 * as + (ln >> 4) + 4 * g, c = ln & 15, qcc = 16 * strip + c;
@@ -337,7 +372,17 @@ __global__ __launch_bounds__(512) void gp_posterior_linv_kernel(PosteriorParams 
           const double df = Xqg[(size_t)a * D + d] * invl[d] - xqs[d * 16 + c];
           d2 = __builtin_fma(df, df, d2);
         }
-        const double kv = os * kernel_from_sqdist<KIND>(d2, exptab);
+        double kv;
+        if (GRAD && c > 0) {
+          kv = 0.0;
+          if (c - 1 < D) {
+            double k0, dk;
+            kernel_and_slope_scaled<KIND>(d2, os, exptab, k0, dk);
+            kv = 2.0 * dk * (xqs[(c - 1) * 16 + c] - Xqg[(size_t)a * D + c - 1] * invl[c - 1]) * invl[c - 1];
+          }
+        } else {
+          kv = os * kernel_from_sqdist<KIND>(d2, exptab);
+        }
         p.cov[((size_t)task * p.Ma + a) * M + qcc] = ys * ys * (kv - cb[e]);
       }
     }
@@ -488,6 +533,53 @@ extern "C" __global__ void scaml_target_finish_kernel(const double* __restrict__
   var[q] = s_all * s_all * (v + noise_add);
 }
 
+// Input gradient of the target posterior (original units) at Mq query points, on top of the weighted sums of the GRAD pass:
+//   d mu* / d x_d  = s ( mu_g[q][1 + d] / s + sum_a alpha_a  dk_nq[a][q][d] )
+//   d var* / d x_d = s^2 ( var_g[q][1 + d] / s^2 - 2 sum_a Z[a][q] dk_nq[a][q][d] )
+//   dk_nq[a][q][d] = cov_g[a][q][1 + d] / s^2 + d/dx_d os_t k_t(x_a, x_q)
+// (ExactGP prediction mu* = mean_q + k_nq . alpha, var* = var_q - k_nq . Knn^-1 k_nq, SURVEY A10, differentiated in x_q; alpha and
+// Z = Knn^-1 Knq come from the value path).  One thread per (query, dimension).
+template <int KIND>
+__global__ void scaml_target_grad_kernel(const double* __restrict__ cov_g, const double* __restrict__ mu_g, const double* __restrict__ var_g,
+                                         const double* __restrict__ Xt, const double* __restrict__ Xq, const double* __restrict__ theta,
+                                         const double* __restrict__ alpha, const double* __restrict__ Z, double s_all,
+                                         const int32_t* __restrict__ info, int n, int Mq, int D, double* __restrict__ dmu,
+                                         double* __restrict__ dvar) {
+  __shared__ double exptab[64];
+  scaml::exp2_table_init(exptab, threadIdx.x);
+  __syncthreads();
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Mq * D) return;
+  const int q = e / D, d = e - q * D;
+  if (info && info[0] > 0) {
+    dmu[e] = dvar[e] = __builtin_nan("");
+    return;
+  }
+  const double os = theta[D], inv_s2 = 1.0 / (s_all * s_all);
+  const double ild = 1.0 / theta[d];
+  const size_t W = (size_t)Mq * 16, col = (size_t)q * 16 + 1 + d;
+  double gm = 0.0, gv = 0.0;
+  for (int a = 0; a < n; ++a) {
+    double d2 = 0.0;
+    for (int j = 0; j < D; ++j) {
+      const double df = (Xq[(size_t)q * D + j] - Xt[(size_t)a * D + j]) / theta[j];
+      d2 = __builtin_fma(df, df, d2);
+    }
+    double k0, dk;
+    scaml::kernel_and_slope_scaled<KIND>(d2, os, exptab, k0, dk);
+    const double dkt = 2.0 * dk * (Xq[(size_t)q * D + d] - Xt[(size_t)a * D + d]) * ild * ild;
+    const double dkn = cov_g[(size_t)a * W + col] * inv_s2 + dkt;
+    gm = __builtin_fma(alpha[a], dkn, gm);
+    gv = __builtin_fma(Z[(size_t)a * Mq + q], dkn, gv);
+  }
+  dmu[e] = mu_g[col] + s_all * gm;
+  dvar[e] = var_g[col] - 2.0 * s_all * s_all * gv;
+}
+template __global__ void scaml_target_grad_kernel<0>(const double*, const double*, const double*, const double*, const double*, const double*,
+                                                      const double*, const double*, double, const int32_t*, int, int, int, double*, double*);
+template __global__ void scaml_target_grad_kernel<1>(const double*, const double*, const double*, const double*, const double*, const double*,
+                                                      const double*, const double*, double, const int32_t*, int, int, int, double*, double*);
+
 template __global__ void scaml::gp_posterior_kernel<0>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_kernel<1>(scaml::PosteriorParams);
 template __global__ void scaml::gp_posterior_cov_kernel<0>(scaml::PosteriorCovParams);
@@ -519,7 +611,9 @@ __global__ void gp_kernel_matrix_kernel(scaml::KernelMatrixParams p) {
 }
 template __global__ void gp_kernel_matrix_kernel<0>(scaml::KernelMatrixParams);
 template __global__ void gp_kernel_matrix_kernel<1>(scaml::KernelMatrixParams);
-template __global__ void scaml::gp_posterior_linv_kernel<0, false>(scaml::PosteriorParams);
-template __global__ void scaml::gp_posterior_linv_kernel<1, false>(scaml::PosteriorParams);
-template __global__ void scaml::gp_posterior_linv_kernel<0, true>(scaml::PosteriorParams);
-template __global__ void scaml::gp_posterior_linv_kernel<1, true>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0, false, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1, false, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0, true, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1, true, false>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<0, true, true>(scaml::PosteriorParams);
+template __global__ void scaml::gp_posterior_linv_kernel<1, true, true>(scaml::PosteriorParams);

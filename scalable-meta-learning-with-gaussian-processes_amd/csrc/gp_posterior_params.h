@@ -26,6 +26,10 @@ struct PosteriorParams {
   const double* VA;
   double* cov;
   int Ma;
+  int pad_;
+  // the Ma leading points of the covariance block when they are not the head of Xq (input-gradient pass: Xq holds the query
+  // points only); NULL: the first Ma rows of Xq
+  const double* Xa;
 };
 
 struct PosteriorCovParams {

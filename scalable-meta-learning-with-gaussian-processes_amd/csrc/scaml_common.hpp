@@ -138,6 +138,28 @@ __device__ __forceinline__ double kernel_from_sqdist_scaled(double d2, double c0
   }
 }
 
+// os k(d2) and os dk / d(d2) of the scaled squared distance d2 (input gradients of the posterior):
+//   RBF      k = os exp(-d2 / 2),                         dk/dd2 = -k / 2
+//   Matern   k = os (1 + sqrt5 r + 5/3 r^2) exp(-sqrt5 r),  dk/dd2 = -(5/6) os (1 + sqrt5 r) exp(-sqrt5 r)   (finite at r = 0)
+template <int KIND>
+__device__ __forceinline__ void kernel_and_slope_scaled(double d2, double os, const double* exp_tab, double& k, double& dk) {
+  if (KIND == 0) {
+    k = os * exp_neg_t<true>(-0.5 * d2, exp_tab);
+    dk = -0.5 * k;
+  } else {
+    const double s5 = 2.2360679774997896964;
+    const double dd = vmin_f64(vmax_f64(d2, 1e-30), 1e5);
+    const double y = (double)__builtin_amdgcn_rsqf((float)dd);
+    const double g = dd * y;
+    const double e = __builtin_fma(-g, y, 1.0);
+    const double r = __builtin_fma(g * e, __builtin_fma(e, 0.375, 0.5), g);
+    const double ex = os * exp_neg_t<false>(-s5 * r, exp_tab);
+    const double lin = __builtin_fma(s5, r, 1.0);
+    k = __builtin_fma((5.0 / 3.0) * r, r, lin) * ex;
+    dk = (-5.0 / 6.0) * lin * ex;
+  }
+}
+
 // x summed over the four lane groups lq (lanes l, l^16, l^32, l^48), result in every lane: gfx950's
 // v_permlane{32,16}_swap exchange half-waves / odd-even rows in one VALU op per dword (no LDS crossbar)
 __device__ __forceinline__ double sum_lane_groups(double x) {

@@ -49,6 +49,7 @@ struct Module {
   hipFunction_t post_cov[2] = {nullptr, nullptr};
   hipFunction_t post_linv[2] = {nullptr, nullptr};
   hipFunction_t post_linv_cov[2] = {nullptr, nullptr};
+  hipFunction_t post_linv_grad[2] = {nullptr, nullptr};
   hipFunction_t wsum = nullptr;
   hipFunction_t linv = nullptr;
   hipFunction_t kmat[2] = {nullptr, nullptr};
@@ -57,6 +58,7 @@ struct Module {
   hipFunction_t tgt_assemble[2] = {nullptr, nullptr};
   hipFunction_t tgt_finish = nullptr;
   hipFunction_t tgt_fit = nullptr;
+  hipFunction_t tgt_grad[2] = {nullptr, nullptr};
   hipFunction_t blk_round = nullptr, blk_finish = nullptr;
   hipFunction_t blk_solve[2][2] = {}, blk_syrk[2] = {nullptr, nullptr};   // solve: [kind][D <= 8]
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
@@ -86,12 +88,15 @@ struct Module {
       if ((e = hipFuncSetAttribute((const void*)post[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
       snprintf(name, sizeof(name), "_ZN5scaml23gp_posterior_cov_kernelILi%dEEEvNS_18PosteriorCovParamsE", kind);
       if ((e = hipModuleGetFunction(&post_cov[kind], mod, name)) != hipSuccess) return e;
-      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb0EEEvNS_15PosteriorParamsE", kind);
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb0ELb0EEEvNS_15PosteriorParamsE", kind);
       if ((e = hipModuleGetFunction(&post_linv[kind], mod, name)) != hipSuccess) return e;
       if ((e = hipFuncSetAttribute((const void*)post_linv[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb1EEEvNS_15PosteriorParamsE", kind);
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb1ELb0EEEvNS_15PosteriorParamsE", kind);
       if ((e = hipModuleGetFunction(&post_linv_cov[kind], mod, name)) != hipSuccess) return e;
       if ((e = hipFuncSetAttribute((const void*)post_linv_cov[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+      snprintf(name, sizeof(name), "_ZN5scaml24gp_posterior_linv_kernelILi%dELb1ELb1EEEvNS_15PosteriorParamsE", kind);
+      if ((e = hipModuleGetFunction(&post_linv_grad[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)post_linv_grad[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&wsum, mod, "scaml_weighted_task_sum_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&linv, mod, "_ZN5scaml14gp_linv_kernelENS_10LinvParamsE")) != hipSuccess) return e;
@@ -121,6 +126,11 @@ struct Module {
       char name[128];
       snprintf(name, sizeof(name), "_Z28scaml_target_assemble_kernelILi%dEEvN5scaml20TargetAssembleParamsE", kind);
       if ((e = hipModuleGetFunction(&tgt_assemble[kind], mod, name)) != hipSuccess) return e;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      snprintf(name, sizeof(name), "_Z24scaml_target_grad_kernelILi%dEEvPKdS1_S1_S1_S1_S1_S1_S1_dPKiiiiPdS4_", kind);
+      if ((e = hipModuleGetFunction(&tgt_grad[kind], mod, name)) != hipSuccess) return e;
     }
     if ((e = hipModuleGetFunction(&tgt_finish, mod, "scaml_target_finish_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&tgt_fit, mod, "scaml_target_fit_kernel")) != hipSuccess) return e;
@@ -535,13 +545,13 @@ int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32
 static int posterior_linv_common(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
                                  const double* y_mean, const double* y_std, const int32_t* n_points, const double* VA, int T, int N,
                                  int M, int Ma, int D, int kind, double* mu, double* var, double* V, double* cov, unsigned flags,
-                                 void* stream) {
+                                 void* stream, bool grad = false, const double* Xa = nullptr) {
   if (T < 0 || N < 1 || M < 0 || D < 1) return SCAML_E_BADARG;
   if (!Xq || !X || !theta || !Linv || !alpha) return SCAML_E_BADARG;
   if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
   if (flags & SCAML_POST_MEAN_ONLY) return SCAML_E_BADARG;   // (use scaml_posterior_batched_f64 for that)
   if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
-  if (VA && (!cov || Ma < 1 || Ma > M)) return SCAML_E_BADARG;
+  if (VA && (!cov || Ma < 1 || (!grad && Ma > M))) return SCAML_E_BADARG;
   if (VA && (Ma > 96 || Ma > N)) return SCAML_E_TOOLARGE;      // six 16-point strips of leading query points at most
   if (T == 0 || M == 0) return SCAML_OK;
   Module& m = module();
@@ -554,13 +564,13 @@ static int posterior_linv_common(const double* Xq, const double* X, const double
   const size_t with_x = base;
   if (base > 160 * 1024) return SCAML_E_TOOLARGE;
   scaml::PosteriorParams p{Xq, X, theta, Linv, nullptr, alpha, y_mean, y_std, n_points, mu, var, V, T, N, M, D, xl ? 1 : 0,
-                           (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0, VA, cov, VA ? Ma : 0};
+                           (flags & SCAML_POST_XQ_PER_TASK) ? 1 : 0, 0, VA, cov, VA ? Ma : 0, 0, Xa};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   const unsigned strips = (unsigned)((M + 15) / 16);
   const unsigned blocks = (unsigned)(((T + 7) / 8) * 8) * strips;   // XCD-aware (task, strip) map inside the kernel
-  e = hipModuleLaunchKernel(VA ? m.post_linv_cov[kind] : m.post_linv[kind], blocks, 1, 1, 512, 1, 1, (unsigned)(xl ? with_x : base), (hipStream_t)stream,
-                            nullptr, config);
+  e = hipModuleLaunchKernel(grad ? m.post_linv_grad[kind] : (VA ? m.post_linv_cov[kind] : m.post_linv[kind]), blocks, 1, 1, 512, 1, 1,
+                            (unsigned)(xl ? with_x : base), (hipStream_t)stream, nullptr, config);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(gp_posterior_linv)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
@@ -578,6 +588,18 @@ int scaml_posterior_linv_cov_f64(const double* Xq, const double* X, const double
   if (!VA || !cov) return SCAML_E_BADARG;
   return posterior_linv_common(Xq, X, theta, Linv, alpha, y_mean, y_std, n_points, VA, T, N, M, Ma, D, kind, mu, var, nullptr, cov,
                                flags, stream);
+}
+
+// (5d) the posterior pass with input gradients: 16 columns per query point = [value, d/dx_0 .. d/dx_{D-1}, zeros]
+int scaml_posterior_linv_grad_f64(const double* Xq, const double* Xa, const double* X, const double* theta, const double* Linv,
+                                  const double* alpha, const double* y_mean, const double* y_std, const int32_t* n_points,
+                                  const double* VA, int T, int N, int Mq, int Ma, int D, int kind, double* mu, double* var, double* cov,
+                                  unsigned flags, void* stream) {
+  if (Mq < 0 || Ma < 0 || D > 15) return D > 15 ? SCAML_E_TOOLARGE : SCAML_E_BADARG;
+  if (Ma > 0 && (!VA || !cov || !Xa)) return SCAML_E_BADARG;
+  if (Mq > (1 << 26)) return SCAML_E_TOOLARGE;
+  return posterior_linv_common(Xq, X, theta, Linv, alpha, y_mean, y_std, n_points, Ma > 0 ? VA : nullptr, T, N, 16 * Mq, Ma > 0 ? Ma : 0, D, kind,
+                               mu, var, nullptr, Ma > 0 ? cov : nullptr, flags, stream, true, Xa);
 }
 
 // ---- (4) gradient of the marginal log-likelihood ------------------------------------------------
@@ -686,6 +708,25 @@ int scaml_target_finish_f64(const double* Knq, const double* Z, const double* al
                   (void*)&info, (void*)&n, (void*)&M, (void*)&mu, (void*)&var};
   e = hipModuleLaunchKernel(m.tgt_finish, (unsigned)((M + 127) / 128), 1, 1, 128, 1, 1, 0, (hipStream_t)stream, args, nullptr);
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_finish)", e); return SCAML_E_LAUNCH; }
+  return SCAML_OK;
+}
+
+int scaml_target_posterior_grad_f64(const double* cov_g, const double* mu_g, const double* var_g, const double* Xt, const double* Xq,
+                                    const double* theta, const double* alpha, const double* Z, double s_all, const int32_t* info, int n,
+                                    int Mq, int D, int kind, double* dmu, double* dvar, void* stream) {
+  if (n < 0 || Mq < 0 || D < 1) return SCAML_E_BADARG;
+  if (!mu_g || !var_g || !Xq || !theta || !dmu || !dvar) return SCAML_E_BADARG;
+  if (n > 0 && (!cov_g || !Xt || !alpha || !Z)) return SCAML_E_BADARG;
+  if (kind != SCAML_KIND_RBF && kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
+  if (!(s_all > 0.0)) return SCAML_E_BADARG;
+  if (Mq == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  void* args[] = {(void*)&cov_g, (void*)&mu_g, (void*)&var_g, (void*)&Xt, (void*)&Xq, (void*)&theta, (void*)&alpha, (void*)&Z, (void*)&s_all,
+                  (void*)&info, (void*)&n, (void*)&Mq, (void*)&D, (void*)&dmu, (void*)&dvar};
+  e = hipModuleLaunchKernel(m.tgt_grad[kind], (unsigned)((Mq * D + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+  if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_grad)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
 

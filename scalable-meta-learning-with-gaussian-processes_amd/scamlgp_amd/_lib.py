@@ -117,6 +117,10 @@ def _load() -> ctypes.CDLL:
     lib.scaml_target_assemble_f64.argtypes = [_dp] * 6 + [c_double, c_double, c_int, c_int, c_int, c_int] + [_dp] * 5 + [c_void_p]
     lib.scaml_target_finish_f64.restype = c_int
     lib.scaml_target_finish_f64.argtypes = [_dp] * 5 + [c_double, c_double, c_double, _dp, c_int, c_int, _dp, _dp, c_void_p]
+    lib.scaml_posterior_linv_grad_f64.restype = c_int
+    lib.scaml_posterior_linv_grad_f64.argtypes = [_dp] * 10 + [c_int] * 6 + [_dp, _dp, _dp, ctypes.c_uint, c_void_p]
+    lib.scaml_target_posterior_grad_f64.restype = c_int
+    lib.scaml_target_posterior_grad_f64.argtypes = [_dp] * 8 + [c_double, _dp, c_int, c_int, c_int, c_int, _dp, _dp, c_void_p]
     lib.scaml_target_fit_max_n.restype = c_int
     lib.scaml_target_fit_max_n.argtypes = [c_int, c_int]
     lib.scaml_target_fit_max_d.restype = c_int
@@ -163,6 +167,8 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_linv_cov_f64",
     "scaml_target_assemble_f64",
     "scaml_target_finish_f64",
+    "scaml_posterior_linv_grad_f64",
+    "scaml_target_posterior_grad_f64",
     "scaml_target_fit_max_n",
     "scaml_target_fit_max_d",
     "scaml_target_fit_workspace_doubles",

@@ -9,8 +9,8 @@ two things ``scamlgp/optimizer.py`` does with the model:
 
 The acquisition optimiser follows botorch's ``optimize_acqf`` recipe -- ``raw_samples`` random candidates, ``num_restarts``
 initial conditions drawn from them (the best one plus a Boltzmann sample of the rest), box-constrained L-BFGS-B over all
-starts jointly, best end point wins -- with every objective evaluation ONE batched posterior call over the starts and
-their central-difference stencils (the HIP posterior has no input-gradient kernel)."""
+starts jointly, best end point wins -- with exact gradients from the posterior's input-gradient kernels (round 3;
+central differences where they do not apply)."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Hashable, Optional, Tuple
@@ -47,26 +47,28 @@ class GraphedAcquisition:
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = af(self.x)
+            self.out = af(self.x)   # a tensor, or a tuple of tensors (value, gradient)
 
-    def __call__(self, X: torch.Tensor) -> torch.Tensor:
+    def __call__(self, X: torch.Tensor):
         if X.shape[0] != self.batch:
             return self.af(X)
         self.x.copy_(X, non_blocking=True)
         self.graph.replay()
-        return self.out.clone()
+        return tuple(o.clone() for o in self.out) if isinstance(self.out, tuple) else self.out.clone()
 
 
 def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samples: int = 1024, num_restarts: int = 10,
                   max_iter: int = 50, generator: Optional[torch.Generator] = None, fd_step: float = 1e-4,
-                  eta: float = 2.0, graph_device: Optional[torch.device] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  eta: float = 2.0, graph_device: Optional[torch.device] = None, analytic_grad: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Maximise ``af`` over [0, 1]^dim; returns (x_best (dim,), af(x_best)).  botorch's ``optimize_acqf`` recipe:
     ``raw_samples`` random candidates -> ``num_restarts`` initial conditions (the best candidate plus a Boltzmann sample
     of the rest, ``initialize_q_batch``) -> ONE box-constrained L-BFGS-B run over all starts jointly (the summed
     acquisition value, which is separable over the starts: botorch's ``gen_candidates_scipy`` does the same) -> the
-    best end point.  Every objective evaluation is one batched posterior call over the starts and their
-    central-difference stencils (one-sided at the box faces).  With ``graph_device`` (the model's GPU) that evaluation
-    is captured into a HIP graph once and replayed per L-BFGS-B step (``GraphedAcquisition``)."""
+    best end point.  Gradients: analytic when the acquisition function offers ``value_and_grad`` and its model the posterior
+    input-gradient kernels (``ScaMLGP.posterior_with_grad``: an evaluation then scores just the R starts); otherwise every
+    objective evaluation is one batched posterior call over the starts and their central-difference stencils (one-sided at the
+    box faces, 2 dim + 1 points per start).  With ``graph_device`` (the model's GPU) the evaluation is captured into a HIP graph
+    once and replayed per L-BFGS-B step (``GraphedAcquisition``)."""
     cand = torch.rand(raw_samples, dim, dtype=torch.float64, generator=generator)
     vals = af(cand).detach().cpu()
     R = min(num_restarts, raw_samples)
@@ -82,9 +84,22 @@ def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samp
     x0 = cand[picks]
     R = x0.shape[0]
     eye = torch.eye(dim, dtype=torch.float64)
-    af_step = GraphedAcquisition(af, R * (2 * dim + 1), dim, graph_device) if graph_device is not None else af
+    analytic = analytic_grad and hasattr(af, "value_and_grad") and getattr(getattr(af, "model", None), "supports_posterior_grad", lambda: False)()
+    if analytic:
+        # exact gradients from the posterior's input-gradient kernels: an evaluation scores the R starts, nothing else
+        vg = GraphedAcquisition(af.value_and_grad, R, dim, graph_device) if graph_device is not None else af.value_and_grad
 
-    def fun(zv: np.ndarray):
+        def fun(zv: np.ndarray):
+            v, g = vg(torch.from_numpy(zv).reshape(R, dim))
+            out = torch.cat([v.reshape(-1), g.reshape(-1)]).detach().cpu()   # one device -> host copy per evaluation
+            f = float(out[:R].sum())
+            if not math.isfinite(f):
+                return float("inf"), np.zeros_like(zv)
+            return -f, -torch.nan_to_num(out[R:]).numpy()
+    else:
+        af_step = GraphedAcquisition(af, R * (2 * dim + 1), dim, graph_device) if graph_device is not None else af
+
+    def fun_fd(zv: np.ndarray):
         x = torch.from_numpy(zv).reshape(R, dim)
         xp = (x.unsqueeze(1) + fd_step * eye).clamp(0.0, 1.0)      # (R, dim, dim): start r shifted along dimension d
         xm = (x.unsqueeze(1) - fd_step * eye).clamp(0.0, 1.0)
@@ -96,7 +111,7 @@ def optimize_acqf(af: Callable[[torch.Tensor], torch.Tensor], dim: int, raw_samp
             return float("inf"), np.zeros_like(zv)
         return -f, -torch.nan_to_num(g).reshape(-1).numpy()
 
-    res = scipy.optimize.minimize(fun, x0.reshape(-1).numpy(), jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * (R * dim),
+    res = scipy.optimize.minimize(fun if analytic else fun_fd, x0.reshape(-1).numpy(), jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * (R * dim),
                                   options=dict(maxiter=max_iter))
     xs = torch.from_numpy(np.clip(res.x, 0.0, 1.0)).reshape(R, dim)
     fin = torch.nan_to_num(af(xs).detach().cpu(), nan=-float("inf"))

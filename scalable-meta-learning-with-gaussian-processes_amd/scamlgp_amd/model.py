@@ -680,6 +680,60 @@ class ScaMLGP:
             cov = cov_s / self.s_all ** 2 + _kernel_torch(xall[:first], xall, theta, self.kind)
         return mean, cov, var_q, theta
 
+    # -- posterior with input gradients (what the acquisition optimiser differentiates through) ------------------------------
+    def supports_posterior_grad(self) -> bool:
+        """The analytic input-gradient path needs training data within the fused covariance block (n <= 96), D <= 15 and the
+        explicit inverse factors of the source stack (SourceGPStack.refresh caches them)."""
+        return 1 <= self.n <= 96 and self._stack.D <= 15 and self._stack.N <= 512 and self.device.type == "cuda"
+
+    def _train_VA(self) -> torch.Tensor:
+        """V = L^-1 K(X_t, train_X) of every source task (T, N, n): fixed for the model's lifetime (sources and training inputs are)."""
+        if getattr(self, "_VA", None) is None:
+            st, f = self._stack, self._stack.fit
+            self._VA = ops.source_posteriors(self.train_X, st.X, st.theta, st.kind, f["L"], f["Linv_diag"], f["alpha"], st.y_mean, st.y_std,
+                                             n_points=st.n_points, want_var=False, keep_V=True, Linv=f["Linv"])["V"]
+        return self._VA
+
+    def _train_prior(self):
+        """The weighted source sums at the training inputs (mu_s (n,), Sigma_s (n, n), var_s (n,)): per weight state."""
+        w = self.weights
+        c = getattr(self, "_train_prior_cache", None)
+        if c is None or not self._same_tensors(c[0], (w,)):
+            c = (((w, w._version),), self._source_prior(self.train_X, self.n))
+            self._train_prior_cache = c
+        return c[1]
+
+    def posterior_with_grad(self, X: torch.Tensor):
+        """Target posterior mean / variance at X (Mq, D) in original units AND their gradients w.r.t. X: (mu (Mq,), var (Mq,),
+        dmu (Mq, D), dvar (Mq, D)).  The reference gets these from torch autograd through ``model.posterior`` inside botorch's
+        optimize_acqf (scamlgp/utils.py:215-224, SURVEY 3.3 HOT LOOP #4); here: one source pass with 16 columns per query point
+        (value + D derivative right-hand sides through the same L^-1 product, scaml_posterior_linv_grad_f64), the weighted task
+        sums, the target GP's value path (assemble / jittered Cholesky / solve / finish) and one contraction kernel
+        (scaml_target_posterior_grad_f64) -- an L-BFGS-B evaluation over R starts scores R points instead of the (2 D + 1) R of a
+        central-difference stencil, with exact gradients."""
+        if not self.supports_posterior_grad():
+            raise NotImplementedError("analytic posterior gradients need 1 <= n <= 96 training points and D <= 15")
+        Xq = torch.as_tensor(X, dtype=torch.float64).reshape(-1, self._stack.D).to(self.device).contiguous()
+        Mq, n = Xq.shape[0], self.n
+        st, f = self._stack, self._stack.fit
+        w_full, active = self._active_tasks()
+        mu_t, cov_tt, var_t = self._train_prior()
+        g = ops.source_posteriors_grad(Xq, self.train_X, st.X, st.theta, st.kind, f["Linv"], f["alpha"], st.y_mean, st.y_std, st.n_points,
+                                       self._train_VA())
+        mu_g, cov_g = ops.weighted_prior_reduce(g["mu"].reshape(st.T, Mq * 16), g["cov"], w_full, active)
+        var_g = ops.weighted_task_sum(g["var"].reshape(st.T, Mq * 16), w_full, 2, active)
+        mu_g, cov_g, var_g = sdist.fused_allreduce([mu_g, cov_g, var_g], self._shard)
+        # the value columns next to the training block: the joint prior the target GP's value path takes
+        cov_s = torch.cat([cov_tt, cov_g.reshape(n, Mq, 16)[:, :, 0]], 1)
+        mean_s = torch.cat([mu_t, mu_g.reshape(Mq, 16)[:, 0]])
+        var_s = torch.cat([var_t, var_g.reshape(Mq, 16)[:, 0]])
+        xall = torch.cat([self.train_X, Xq], 0)
+        theta = self.theta
+        full = ops.target_posterior_full(cov_s, mean_s, var_s, xall, theta, self.train_targets, self._m_all_f, self._s_all_f, self.kind)
+        dmu, dvar = ops.target_posterior_grad(cov_g, mu_g, var_g, self.train_X, Xq, theta, full["alpha"], full["Z"], self._s_all_f,
+                                              full["info"], self.kind)
+        return full["mu"], full["var"], dmu, dvar
+
     def posterior(self, X: torch.Tensor, observation_noise: bool = False) -> TargetPosterior:
         """Target posterior at X (M, D) in original units (A10).  The source prior is evaluated ONCE at
         cat(train_X, X) -- train block, cross block and query diagonal -- instead of once per query as the

@@ -456,6 +456,14 @@ def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Ten
     (n + M).  scaml_target_assemble_f64 -> scaml_potrf_batched_f64 (T = 1, jitter ladder) -> scaml_cho_solve_batched_f64
     -> scaml_target_finish_f64: four launches, no host synchronisation.  A factorisation that fails even with jitter shows as NaN
     in mu / var (the status stays on the device).  Returns (mu (M,), var (M,), info (1,), jitter (1,))."""
+    f = target_posterior_full(cov_s, mean_s, var_s, Xall, theta, train_targets, m_all, s_all, kind, observation_noise)
+    return f["mu"], f["var"], f["info"], f["jitter"]
+
+
+def target_posterior_full(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Tensor, Xall: torch.Tensor, theta: torch.Tensor,
+                          train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False) -> Dict[str, torch.Tensor]:
+    """``target_posterior`` with its intermediates: dict(mu, var, info, jitter, alpha (n,) = Knn^-1 resid, Z (n, M) = Knn^-1 Knq) --
+    alpha and Z are what the input gradient of the posterior contracts against (``target_posterior_grad``)."""
     n = int(train_targets.shape[0])
     W, D = Xall.shape
     M = W - n
@@ -478,13 +486,77 @@ def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Ten
         _lib.check_rc(rc, "scaml_target_assemble_f64")
         f = potrf_batched(Knn, resid, want_linv=True)
         mu, var = torch.empty((M,), **f64), torch.empty((M,), **f64)
+        Z = None
         if M > 0:
             Z = cho_solve(f["L"], f["Linv_diag"], Knq)
             rc = _lib.lib.scaml_target_finish_f64(_ptr(Knq), _ptr(Z), _ptr(f["alpha"]), _ptr(mean_q), _ptr(var_q), float(m_all), float(s_all),
                                                   float(theta[D + 1]) if observation_noise else 0.0, _ptr(f["info"]), n, M, _ptr(mu), _ptr(var),
                                                   _stream_handle())
             _lib.check_rc(rc, "scaml_target_finish_f64")
-    return mu, var, f["info"], f["jitter"]
+    return dict(mu=mu, var=var, info=f["info"], jitter=f["jitter"], alpha=f["alpha"][0], Z=None if Z is None else Z[0])
+
+
+def source_posteriors_grad(Xq: torch.Tensor, Xa: Optional[torch.Tensor], X: torch.Tensor, theta: torch.Tensor, kind: int, Linv: torch.Tensor,
+                           alpha: torch.Tensor, y_mean: Optional[torch.Tensor] = None, y_std: Optional[torch.Tensor] = None,
+                           n_points: Optional[torch.Tensor] = None, VA: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Source posteriors at Xq (Mq, D) WITH their input gradients, one launch of scaml_posterior_linv_grad_f64: dict(mu (T, Mq, 16),
+    var (T, Mq, 16), cov (T, Ma, Mq * 16) or None); column 0 of each 16-block is the value, columns 1 .. D the derivative w.r.t.
+    x_0 .. x_{D-1}.  Xa (Ma, D), VA (T, N, Ma): the leading points of the covariance block (the target's training inputs) and their
+    V = L^-1 K(X, Xa) from ``source_posteriors(..., keep_V=True)``."""
+    T, N, D = X.shape
+    Mq = Xq.shape[0]
+    X = _check(X, "X")
+    Xq = _check(Xq, "Xq", (Mq, D))
+    theta = _check(theta, "theta", (T, D + 2))
+    Linv = _check(Linv, "Linv", (T, N, N))
+    alpha = _check(alpha, "alpha", (T, N))
+    Ma = 0 if VA is None else int(VA.shape[-1])
+    if Ma:
+        VA = _check(VA, "VA", (T, N, Ma))
+        Xa = _check(Xa, "Xa", (Ma, D))
+    if y_mean is not None:
+        y_mean = _check(y_mean, "y_mean", (T,))
+    if y_std is not None:
+        y_std = _check(y_std, "y_std", (T,))
+    if n_points is not None:
+        n_points = _check(n_points, "n_points", (T,), torch.int32)
+    dev = X.device
+    with torch.cuda.device(dev):
+        mu = torch.empty((T, Mq, 16), dtype=torch.float64, device=dev)
+        var = torch.empty((T, Mq, 16), dtype=torch.float64, device=dev)
+        cov = torch.empty((T, Ma, Mq * 16), dtype=torch.float64, device=dev) if Ma else None
+        rc = _lib.lib.scaml_posterior_linv_grad_f64(_ptr(Xq), _ptr(Xa) if Ma else None, _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean),
+                                                    _ptr(y_std), _ptr(n_points), _ptr(VA) if Ma else None, T, N, Mq, Ma, D, int(kind), _ptr(mu),
+                                                    _ptr(var), _ptr(cov), 0, _stream_handle())
+    _lib.check_rc(rc, "scaml_posterior_linv_grad_f64")
+    return dict(mu=mu, var=var, cov=cov)
+
+
+def target_posterior_grad(cov_g: Optional[torch.Tensor], mu_g: torch.Tensor, var_g: torch.Tensor, Xt: torch.Tensor, Xq: torch.Tensor,
+                          theta: torch.Tensor, alpha: Optional[torch.Tensor], Z: Optional[torch.Tensor], s_all: float,
+                          info: Optional[torch.Tensor], kind: int):
+    """d mu* / d x and d var* / d x (Mq, D) of the target posterior from the weighted task sums of ``source_posteriors_grad``
+    (cov_g (n, Mq * 16), mu_g / var_g (Mq * 16)) and the value path's alpha (n,), Z (n, Mq).  scaml_target_posterior_grad_f64."""
+    Mq, D = Xq.shape
+    n = 0 if cov_g is None else int(cov_g.shape[0])
+    mu_g = _check(mu_g.reshape(-1), "mu_g", (Mq * 16,))
+    var_g = _check(var_g.reshape(-1), "var_g", (Mq * 16,))
+    Xq = _check(Xq, "Xq")
+    theta = _check(theta, "theta", (D + 2,))
+    if n:
+        cov_g = _check(cov_g, "cov_g", (n, Mq * 16))
+        Xt = _check(Xt, "Xt", (n, D))
+        alpha = _check(alpha, "alpha", (n,))
+        Z = _check(Z, "Z", (n, Mq))
+    dev = Xq.device
+    with torch.cuda.device(dev):
+        dmu = torch.empty((Mq, D), dtype=torch.float64, device=dev)
+        dvar = torch.empty((Mq, D), dtype=torch.float64, device=dev)
+        rc = _lib.lib.scaml_target_posterior_grad_f64(_ptr(cov_g) if n else None, _ptr(mu_g), _ptr(var_g), _ptr(Xt) if n else None, _ptr(Xq),
+                                                      _ptr(theta), _ptr(alpha) if n else None, _ptr(Z) if n else None, float(s_all), _ptr(info), n, Mq, D,
+                                                      int(kind), _ptr(dmu), _ptr(dvar), _stream_handle())
+    _lib.check_rc(rc, "scaml_target_posterior_grad_f64")
+    return dmu, dvar
 
 
 def mll_backward_workspace(T: int, N: int, D: int, device) -> Dict[str, torch.Tensor]:

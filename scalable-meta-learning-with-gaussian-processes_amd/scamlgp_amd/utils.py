@@ -252,6 +252,14 @@ class UpperConfidenceBound:
         mvn = self.model.posterior(_single_q(X)).mvn
         return _drop_q(X, -mvn.mean + torch.sqrt(self.beta * mvn.variance.clamp_min(0.0)))
 
+    def value_and_grad(self, X: torch.Tensor):
+        """(value (M,), d value / d X (M, D)) from the model's analytic posterior gradients (ScaMLGP.posterior_with_grad)."""
+        mu, var, dmu, dvar = self.model.posterior_with_grad(X)
+        sd = torch.sqrt(self.beta * var.clamp_min(0.0))
+        # d sqrt(beta var) = beta dvar / (2 sqrt(beta var)); zero where the variance is clamped
+        coef = torch.where(var > 0, 0.5 * self.beta / sd.clamp_min(1e-300), torch.zeros_like(sd))
+        return -mu + sd, -dmu + coef.unsqueeze(-1) * dvar
+
 
 class ExpectedImprovement:
     """botorch analytic ExpectedImprovement(model, best_f, maximize=False) (scamlgp/optimizer.py:96-98):
@@ -267,3 +275,14 @@ class ExpectedImprovement:
         pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
         cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
         return _drop_q(X, sigma * (pdf + u * cdf))
+
+    def value_and_grad(self, X: torch.Tensor):
+        """(EI (M,), d EI / d X (M, D)): d EI = -Phi(u) d mu + phi(u) d sigma, d sigma = d var / (2 sigma) (zero where the variance
+        sits on the 1e-9 floor), from the model's analytic posterior gradients."""
+        mu, var, dmu, dvar = self.model.posterior_with_grad(X)
+        sigma = var.clamp_min(1e-9).sqrt()
+        u = -(mu - self.best_f) / sigma
+        pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+        cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+        dsig = torch.where(var > 1e-9, 0.5 / sigma, torch.zeros_like(sigma)).unsqueeze(-1) * dvar
+        return sigma * (pdf + u * cdf), -cdf.unsqueeze(-1) * dmu + pdf.unsqueeze(-1) * dsig
