@@ -523,9 +523,12 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
         // curvature pair, then the step
         double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
         const int slot = head;
+        // (the pair lives in the subspace of the variables that were free in this step and still are: a weight that sat on, or
+        //  ran into, the bound contributes a projected step and a gradient change that say nothing about the curvature there)
         for (int i = c.tid; i < P; i += c.nthr) {
           const double gi = -gn[i];
-          const double sv = xn[i] - x[i], yv = gi - g[i];
+          const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
+          const double sv = fr ? xn[i] - x[i] : 0.0, yv = fr ? gi - g[i] : 0.0;
           sy += sv * yv;
           ss += sv * sv;
           yy += yv * yv;
@@ -537,8 +540,9 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
         for (int i = c.tid; i < P; i += c.nthr) {
           const double gi = -gn[i];
           if (push) {
-            S[(size_t)slot * P + i] = xn[i] - x[i];
-            Y[(size_t)slot * P + i] = gi - g[i];
+            const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
+            S[(size_t)slot * P + i] = fr ? xn[i] - x[i] : 0.0;
+            Y[(size_t)slot * P + i] = fr ? gi - g[i] : 0.0;
           }
           x[i] = xn[i];
           g[i] = gi;
@@ -560,7 +564,15 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
         else if (it >= p.max_iter) { go_final = true; }
         else new_dir = true;
       } else {
-        t *= 0.5;
+        // backtrack: the minimiser of the parabola through f, its slope along the projected step, and the trial value -- kept inside
+        // [0.1 t, 0.5 t]; a trial that is not finite just halves
+        double tn = 0.5 * t;
+        if (tf_finite(fn) && dec < 0.0) {
+          const double tq = -0.5 * dec * t / (fn - f - dec);   // slope along the step = dec / t
+          if (tq > 0.1 * t && tq < 0.5 * t) tn = tq;
+          else if (tq <= 0.1 * t) tn = 0.1 * t;
+        }
+        t = tn;
         if (++ls >= p.max_ls) { status = 3; go_final = true; }
       }
     }

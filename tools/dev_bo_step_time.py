@@ -23,3 +23,4 @@ for step in range(3):
     t0 = time.perf_counter(); x = loop.suggest(); torch.cuda.synchronize(); t1 = time.perf_counter()
     loop.report(x, obj(x)); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"step {step}: suggest {t1 - t0:.3f} s, report (refit) {t2 - t1:.3f} s, n = {loop.model.n}")
+print("last refit stats [iterations, evaluations, status, -]:", loop.model.last_fit_info["stats"].cpu().tolist(), "mll", loop.model.last_fit_info["objective"].cpu().tolist())
