@@ -163,6 +163,11 @@ int scaml_posterior_cov_f64(const double* Xq, const double* theta, const double*
  */
 int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N, double* Linv,
                            void* stream);
+/* The same inverse factor with only the block rows at or below each 16-column strip's diagonal block written (the 16 x 16
+ * diagonal blocks complete, zeros above the diagonal inside them): what scaml_posterior_linv*_f64 read.
+ * Everything above is left untouched -- half of the matrix not written (67 of 134 MB at T = 256, N = 256). */
+int scaml_linv_batched_lower_f64(const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N, double* Linv,
+                                 void* stream);
 int scaml_posterior_linv_f64(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
                              const double* y_mean, const double* y_std, const int32_t* n_points, int T, int N, int M, int D,
                              int kind, double* mu, double* var, double* V, unsigned flags, void* stream);

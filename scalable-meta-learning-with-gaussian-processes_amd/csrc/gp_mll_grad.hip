@@ -39,9 +39,12 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
     continue;
   }
   const int qc = 16 * strip + lc;  // column of the inverse owned by this lane
-  // rows above the strip are zero
-  for (int r = lq; r < 16 * strip && r < N; r += 4)
-    if (qc < N) Og[(size_t)r * N + qc] = 0.0;
+  // rows above the strip are zero (half of the dense matrix: 67 MB of the 134 MB this kernel writes at T = 256, N = 256 -- skipped
+  // for callers that only ever read block rows at or below the diagonal block, as the posterior kernels do)
+  if (!p.lower_only) {
+    for (int r = lq; r < 16 * strip && r < N; r += 4)
+      if (qc < N) Og[(size_t)r * N + qc] = 0.0;
+  }
   // acc -= sum_{strip <= j < kb} L[kb, j] V_j.  One workgroup per task at T >= 256 means ONE wave per SIMD: nobody
   // hides this wave's load latency, so the L row segments are fetched four tiles ahead -- across the end of a block
   // row into the first tiles of the next -- and W_kb one block ahead (subst_accumulate looks one tile ahead).

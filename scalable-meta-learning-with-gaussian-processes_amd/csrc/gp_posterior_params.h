@@ -67,6 +67,7 @@ struct LinvParams {
   const int32_t* n_points;  // (T) or NULL
   double* Linv;             // (T, N, N) out: L^-1 (dense, zero above the diagonal)
   int T, N;
+  int lower_only;           // 1: the block rows above a strip's diagonal block are not written (callers that never read them)
 };
 
 struct MllGradParams {

@@ -55,7 +55,11 @@ struct TfCtx {
   int n, T, D, P, E, kind;
   // LDS
   double *Ap, *Tp, *Xs, *col, *piv, *rs, *alpha, *vv, *w, *w2, *theta, *dth, *invl, *part, *red, *sc;
+  // matrix-core path (n <= 112): 16 x 16 tiles at pitch 17, lower block triangle, tile (i, j) at (i (i + 1) / 2 + j) * TF_TS
+  double *Lt, *Xt;
+  int nb, mfma;
 };
+constexpr int TF_TP = 17, TF_TS = 16 * TF_TP;
 
 TF_DEV int tf_idxL(int a, int b) { return a * (a + 1) / 2 + b; }
 TF_DEV int tf_rowT(int j, int n) { return j * n - j * (j - 1) / 2 - j; }   // row j of the upper-packed block: (j, k), k >= j, at tf_rowT(j) + k
@@ -144,6 +148,245 @@ TF_DEV void tf_kernel(int kind, double d2, double& kk, double& dk) {
   }
 }
 
+#ifndef SCAML_HOST_EMUL
+// ---- the factorisation on the matrix cores (n <= 112) ------------------------------------------------------------------------
+// The column-by-column elimination above costs a barrier, an LDS round trip for the pivot and a reciprocal PER COLUMN: 2 us each,
+// 163 us of a 228-us evaluation at n = 80 -- the vector unit idles on latencies.  Here: blocked Cholesky on 16 x 16 tiles in LDS.
+//   per block column K:  wave 0 factors the diagonal tile IN REGISTERS (a lane holds a row; pivots and column entries travel by
+//                        v_readlane, no LDS round trip, no barrier) and inverts it (W_K = L_KK^-1, a lane per column);
+//                        panel  L_iK = A_iK W_K^T  and trailing update  A_ij -= L_iK L_jK^T  as 4 v_mfma_f64_16x16x4 per tile
+//   X = L^-1             by block columns (X_kk = W_k, X_ik = -W_i sum_j L_ij X_jk): the accumulator layout of one product IS the
+//                        B-operand layout of the next (lane (lc, lq) register m = element [4 m + lq][lc])
+//   v = X r, alpha = X^T v, K^-1 = X^T X by tiles, G = (alpha alpha^T - K^-1) / 2 packed into the (then free) L region.
+// Three barriers per BLOCK column instead of one per column.  Returns 0 or the 1-based index of the failing pivot.
+TF_DEV void tf_settle(d4_t& v) { asm volatile("s_nop 15\n\ts_nop 2" : "+v"(v)); }   // gfx950: an MFMA's last result pair is not interlocked
+TF_DEV int tf_tile(int i, int j) { return (i * (i + 1) / 2 + j) * TF_TS; }
+
+TF_DEV int tf_factor_mfma(const TfCtx& c, const TargetFitParams& p, double os, double noise, double jit, double& quad, double& logdet) {
+  const int n = c.n, T = c.T, D = c.D, E = c.E, nb = c.nb;
+  const int lane = c.lane, lc = lane & 15, lq = lane >> 4;
+  const double inv_s = 1.0 / p.s_all;
+  // ---- build: lower block triangle of K (+ noise + jitter), identity padding past n; residual r into vv ----
+  const int ntile = nb * (nb + 1) / 2;
+  for (int e = c.tid; e < ntile * 256; e += c.nthr) {
+    const int t = e >> 8, r = (e >> 4) & 15, cc = e & 15;
+    int ti, tj;
+    tf_decode(t, ti, tj);
+    const int a = 16 * ti + r, b = 16 * tj + cc;
+    double val = a == b ? 1.0 : 0.0;
+    if (a < n && b < n) {
+      val = 0.0;
+      if (b <= a) {
+        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        const double* cp = p.covs_p + tf_idxL(a, b);
+        int i = 0;
+        for (; i + 8 <= T; i += 8) {
+          double x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = cp[(size_t)(i + j) * E];
+          acc += c.w2[i] * x[0] + c.w2[i + 4] * x[4];
+          acc1 += c.w2[i + 1] * x[1] + c.w2[i + 5] * x[5];
+          acc2 += c.w2[i + 2] * x[2] + c.w2[i + 6] * x[6];
+          acc3 += c.w2[i + 3] * x[3] + c.w2[i + 7] * x[7];
+        }
+        for (; i < T; ++i) acc += c.w2[i] * cp[(size_t)i * E];
+        acc = (acc + acc1) + (acc2 + acc3);
+        double k = os;
+        if (a != b) {
+          double d2 = 0.0;
+          for (int d = 0; d < D; ++d) {
+            const double df = (c.Xs[a * D + d] - c.Xs[b * D + d]) * c.invl[d];
+            d2 += df * df;
+          }
+          double kk, dk;
+          tf_kernel(c.kind, d2, kk, dk);
+          k = os * kk;
+        } else {
+          k += noise + jit;
+        }
+        val = acc + k;
+      }
+    }
+    c.Lt[t * TF_TS + r * TF_TP + cc] = val;
+  }
+  for (int b = c.tid; b < 16 * nb; b += c.nthr) {
+    double rv = 0.0;
+    if (b < n) {
+      double m = 0.0, m1 = 0.0;
+      int i = 0;
+      for (; i + 4 <= T; i += 4) {
+        const double x0 = p.means_t[(size_t)i * n + b], x1 = p.means_t[(size_t)(i + 1) * n + b], x2 = p.means_t[(size_t)(i + 2) * n + b],
+                     x3 = p.means_t[(size_t)(i + 3) * n + b];
+        m += c.w[i] * x0 + c.w[i + 2] * x2;
+        m1 += c.w[i + 1] * x1 + c.w[i + 3] * x3;
+      }
+      for (; i < T; ++i) m += c.w[i] * p.means_t[(size_t)i * n + b];
+      rv = p.y[b] - (m + m1 - p.m_all) * inv_s;
+    }
+    c.vv[b] = rv;
+  }
+  if (c.tid == 0) c.sc[0] = 0.0;   // failure word
+  TF_SYNC();
+  TF_STAMP(1);
+  // ---- blocked Cholesky ----
+  for (int K = 0; K < nb; ++K) {
+    if (c.wave == 0) {
+      // diagonal tile in registers: lane l (and its three mirrors l + 16 m) holds row l & 15
+      double* Dt = c.Lt + tf_tile(K, K);
+      double row[16], rinv[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) row[b] = Dt[lc * TF_TP + b];
+      int bad = 0;
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) {
+        const double pv = readlane_f64(row[cc], cc);
+        if (!(pv > 0.0) && bad == 0) bad = 16 * K + cc + 1;
+        const double rsq = rsqrt_pos(pv);
+        rinv[cc] = rsq;                                          // 1 / L[cc][cc]
+        const double x = lc == cc ? pv * rsq : row[cc] * rsq;   // L[l][cc] for l >= cc (rows above hold junk that is never read)
+        row[cc] = x;
+#pragma unroll
+        for (int b = cc + 1; b < 16; ++b) {
+          const double xb = readlane_f64(x, b);                  // L[b][cc]
+          row[b] = __builtin_fma(-x, xb, row[b]);                 // (only b <= l matters)
+        }
+      }
+      // W = L^-1, a lane per COLUMN: w[r] = W[r][lc] by forward substitution, the rows of L broadcast by readlane
+      double wv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double sacc = r == lc ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sacc = __builtin_fma(-readlane_f64(row[k], r), wv[k], sacc);   // L[r][k] W[k][lc]
+        wv[r] = r < lc ? 0.0 : sacc * rinv[r];
+      }
+      if (lane < 16) {
+        double* Wt = c.Xt + tf_tile(K, K);
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+          Dt[lc * TF_TP + b] = b <= lc ? row[b] : 0.0;
+          Wt[b * TF_TP + lc] = wv[b];
+        }
+        if (16 * K + lc < n) c.piv[16 * K + lc] = row[lc];   // diag(L): logdet = 2 sum log
+      }
+      if (lane == 0 && bad) c.sc[0] = (double)bad;
+    }
+    TF_SYNC();
+    const int fail = (int)c.sc[0];
+    if (fail) return fail;
+    // panel: L_iK = A_iK W_K^T   (A operand: A_iK[lc][4 m + lq], B operand: (W^T)[4 m + lq][lc] = W[lc][4 m + lq])
+    {
+      const double* Wt = c.Xt + tf_tile(K, K);
+      double wb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) wb[m] = Wt[lc * TF_TP + 4 * m + lq];
+      for (int i = K + 1 + c.wave; i < nb; i += c.nwave) {
+        double* At = c.Lt + tf_tile(i, K);
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[lc * TF_TP + 4 * m + lq], wb[m], acc, 0, 0, 0);
+        tf_settle(acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) At[(lq + 4 * g) * TF_TP + lc] = acc[g];
+      }
+    }
+    TF_SYNC();
+    // trailing update: A_ij -= L_iK L_jK^T, K < j <= i
+    {
+      const int m1 = nb - K - 1, cnt = m1 * (m1 + 1) / 2;
+      for (int q = c.wave; q < cnt; q += c.nwave) {
+        int ii, jj;
+        tf_decode(q, ii, jj);
+        const int i = K + 1 + ii, j = K + 1 + jj;
+        const double* Li = c.Lt + tf_tile(i, K);
+        const double* Lj = c.Lt + tf_tile(j, K);
+        double* At = c.Lt + tf_tile(i, j);
+        d4_t acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = At[(lq + 4 * g) * TF_TP + lc];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[lc * TF_TP + 4 * m + lq], Lj[lc * TF_TP + 4 * m + lq], acc, 0, 0, 0);
+        tf_settle(acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) At[(lq + 4 * g) * TF_TP + lc] = acc[g];
+      }
+    }
+    TF_SYNC();
+  }
+  TF_STAMP(2);
+  // ---- X = L^-1 by block columns: X_ik = -W_i sum_{j = k}^{i - 1} L_ij X_jk ----
+  for (int k = c.wave; k < nb; k += c.nwave) {
+    for (int i = k + 1; i < nb; ++i) {
+      d4_t sacc = {0.0, 0.0, 0.0, 0.0};
+      for (int j = k; j < i; ++j) {
+        const double* Lij = c.Lt + tf_tile(i, j);
+        const double* Xjk = c.Xt + tf_tile(j, k);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lij[lc * TF_TP + 4 * m + lq], Xjk[(4 * m + lq) * TF_TP + lc], sacc, 0, 0, 0);
+      }
+      tf_settle(sacc);
+      const double* Wi = c.Xt + tf_tile(i, i);
+      d4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) x = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wi[lc * TF_TP + 4 * m + lq], sacc[m], x, 0, 0, 0);
+      tf_settle(x);
+      double* Xik = c.Xt + tf_tile(i, k);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Xik[(lq + 4 * g) * TF_TP + lc] = x[g];
+    }
+  }
+  TF_SYNC();
+  // ---- v = X r, quad, logdet; alpha = X^T v ----
+  double qd = 0.0, ld = 0.0;
+  for (int a = c.tid; a < n; a += c.nthr) {
+    const int ta = a >> 4, ra = a & 15;
+    double sacc = 0.0;
+    for (int b = 0; b <= a; ++b) sacc += c.Xt[tf_tile(ta, b >> 4) + ra * TF_TP + (b & 15)] * c.vv[b];
+    c.rs[a] = sacc;   // v
+    qd += sacc * sacc;
+    ld += 2.0 * log(c.piv[a]);
+  }
+  quad = tf_block_sum(c, qd);
+  logdet = tf_block_sum(c, ld);
+  for (int b = c.tid; b < n; b += c.nthr) {
+    const int tb = b >> 4, rb = b & 15;
+    double sacc = 0.0;
+    for (int a = b; a < n; ++a) sacc += c.Xt[tf_tile(a >> 4, tb) + (a & 15) * TF_TP + rb] * c.rs[a];
+    c.alpha[b] = sacc;
+  }
+  TF_SYNC();
+  TF_STAMP(3);
+  TF_STAMP(4);
+  // ---- K^-1 = X^T X by tiles, G = (alpha alpha^T - K^-1) / 2 (off-diagonal doubled) packed into the L region ----
+  // (every L tile has been read for the last time before the barrier above)
+  {
+    const int cnt = nb * (nb + 1) / 2;
+    for (int q = c.wave; q < cnt; q += c.nwave) {
+      int ta, tb;
+      tf_decode(q, ta, tb);
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = ta; k < nb; ++k) {
+        const double* Xa = c.Xt + tf_tile(k, ta);
+        const double* Xb = c.Xt + tf_tile(k, tb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(4 * m + lq) * TF_TP + lc], Xb[(4 * m + lq) * TF_TP + lc], acc, 0, 0, 0);
+      }
+      tf_settle(acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int a = 16 * ta + lq + 4 * g, b = 16 * tb + lc;
+        if (a < n && b <= a) {
+          const double gv = 0.5 * (c.alpha[a] * c.alpha[b] - acc[g]);
+          c.Ap[tf_idxL(a, b)] = a == b ? gv : 2.0 * gv;
+        }
+      }
+    }
+  }
+  TF_SYNC();
+  return 0;
+}
+#endif
+
 // One evaluation at z (P doubles, global): returns mll (every thread) and, if gz != nullptr, d mll / d z.
 // info_out / jit_out: status of the factorisation (thread 0 writes them if given).  A matrix that is not positive definite
 // even with the largest jitter gives NaN.
@@ -170,8 +413,17 @@ TF_DEV double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z,
   const double os = c.theta[D], noise = c.theta[D + 1];
   int fail = 0;
   double jit = 0.0;
+  double quad_m = 0.0, logdet_m = 0.0;
   for (int attempt = 0; attempt < 4; ++attempt) {
     jit = attempt == 0 ? 0.0 : (attempt == 1 ? 1e-8 : (attempt == 2 ? 1e-7 : 1e-6));
+#ifndef SCAML_HOST_EMUL
+    if (c.mfma) {
+      fail = tf_factor_mfma(c, p, os, noise, jit, quad_m, logdet_m);
+      if (!fail) break;
+      TF_SYNC();
+      continue;
+    }
+#endif
     // ---- build ----
     for (int e = c.tid; e < E; e += c.nthr) {
       int a, b;
@@ -305,25 +557,29 @@ TF_DEV double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z,
 #endif
   }
   // ---- pivots, v = L^-1 r, quad, logdet ----
-  TF_STAMP(2);
+  if (!c.mfma) TF_STAMP(2);
   double ld = 0.0;
-  for (int k = c.tid; k < n; k += c.nthr) {
-    const double pv = c.Ap[tf_idxL(k, k)];
-    const double r = 1.0 / sqrt(pv);
-    c.piv[k] = pv;
-    c.rs[k] = r;
-    c.vv[k] = c.Ap[tf_idxL(n, k)] * r;
-    ld += log(pv);
+  if (!c.mfma) {
+    for (int k = c.tid; k < n; k += c.nthr) {
+      const double pv = c.Ap[tf_idxL(k, k)];
+      const double r = 1.0 / sqrt(pv);
+      c.piv[k] = pv;
+      c.rs[k] = r;
+      c.vv[k] = c.Ap[tf_idxL(n, k)] * r;
+      ld += log(pv);
+    }
   }
   // log priors ride in the same reduction
   double lp = 0.0;
   for (int i = c.tid; i < D + 2; i += c.nthr) lp += tf_prior_logp(i < D ? sp.ls_prior : (i == D ? sp.os_prior : sp.nz_prior), c.theta[i]);
   for (int i = c.tid; i < T; i += c.nthr) lp += tf_prior_logp(sp.w_prior, c.w[i]);
-  const double quad = -c.Ap[tf_idxL(n, n)];
-  const double logdet = tf_block_sum(c, ld);
+  const double quad = c.mfma ? quad_m : -c.Ap[tf_idxL(n, n)];
+  double logdet = tf_block_sum(c, ld);
+  if (c.mfma) logdet = logdet_m;
   const double logprior = tf_block_sum(c, lp);
   const double value = (-0.5 * (quad + logdet + n * 1.8378770664093453) + logprior) / n;
   if (!gz) return value;
+  if (!c.mfma) {
   TF_STAMP(3);
   // ---- U = L^-T scaled: U[j][k] = (L^-1)[k][j], rows j, columns k >= j ----
   for (int j = c.wave; j < n; j += c.nwave) {
@@ -362,6 +618,7 @@ TF_DEV double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z,
     c.Ap[e] = a == b ? g : 2.0 * g;
   }
   TF_SYNC();
+  }   // (column-by-column path; the matrix-core path left G in Ap and alpha in place)
   const double inv_n = 1.0 / n;
   TF_STAMP(5);
   // ---- d / d w_i: one wave per task ----
@@ -643,16 +900,28 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
   }
 }
 
-TF_DEV void tf_carve(TfCtx& c, double* lds, int n, int T, int D, int nwave) {
+TF_DEV void tf_carve(TfCtx& c, double* lds, int n, int T, int D, int nwave, int mfma) {
   double* q = lds;
-  c.Ap = q; q += (n + 1) * (n + 2) / 2;
-  c.Tp = q; q += n * (n + 1) / 2;
+  c.nb = (n + 15) / 16;
+  c.mfma = mfma;
+  if (mfma) {
+    // two block triangles of 16 x 17 tiles: L (later the packed G), X = L^-1
+    const int tiles = c.nb * (c.nb + 1) / 2;
+    c.Lt = q; q += tiles * TF_TS;
+    c.Xt = q; q += tiles * TF_TS;
+    c.Ap = c.Lt;
+    c.Tp = c.Xt;
+  } else {
+    c.Lt = c.Xt = nullptr;
+    c.Ap = q; q += (n + 1) * (n + 2) / 2;
+    c.Tp = q; q += n * (n + 1) / 2;
+  }
   c.Xs = q; q += n * D;
   c.col = q; q += 2 * (n + 1);
   c.piv = q; q += n;
   c.rs = q; q += n;
   c.alpha = q; q += n;
-  c.vv = q; q += n;
+  c.vv = q; q += n + 16;
   c.w = q; q += T;
   c.w2 = q; q += T;
   c.theta = q; q += D + 2;
@@ -682,7 +951,7 @@ extern "C" __global__ __launch_bounds__(TF_MAX_THREADS) void scaml_target_fit_ke
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: every row index derived from it is SALU work, off the vector unit)
   c.nwave = blockDim.x >> 6;
   c.n = p.n; c.T = p.T; c.D = p.D; c.P = p.D + 2 + p.T; c.E = p.n * (p.n + 1) / 2; c.kind = p.kind;
-  tf_carve(c, tf_lds, p.n, p.T, p.D, c.nwave);
+  tf_carve(c, tf_lds, p.n, p.T, p.D, c.nwave, p.use_mfma);
   tf_main(c, p, blockIdx.x);
 }
 #endif

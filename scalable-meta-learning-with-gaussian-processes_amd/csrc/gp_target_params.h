@@ -39,6 +39,7 @@ struct TargetFitParams {
   int kind;
   int mode;                // 0: value + gradient at z, 1: L-BFGS from z
   int max_iter, history, max_ls;
+  int use_mfma;            // 1: factorisation on the matrix cores (16 x 16 tiles in LDS; n <= 112), 0: column-by-column elimination
   double gtol, ftol;
 };
 

@@ -514,10 +514,10 @@ int scaml_weighted_prior_reduce_f64(const double* mu, const double* cov, const d
 
 // ---- explicit inverse factor + posteriors from it -------------------------------------------------
 static int launch_linv(Module& m, const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N,
-                       double* Linv, void* stream) {
+                       double* Linv, void* stream, int lower_only = 0) {
   const int nb = (N + 15) / 16, np = nb * 16;
   const int waves = (np * 16 * 8 * 4 <= 160 * 1024) ? 4 : ((np * 16 * 8 * 2 <= 160 * 1024) ? 2 : 1);
-  scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N};
+  scaml::LinvParams p{L, Linv_diag, n_points, Linv, T, N, lower_only};
   size_t psize = sizeof(p);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &psize, HIP_LAUNCH_PARAM_END};
   // one workgroup per task takes all strips (balanced over its waves); small stacks are split over more
@@ -540,6 +540,18 @@ int scaml_linv_batched_f64(const double* L, const double* Linv_diag, const int32
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   return launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
+}
+
+int scaml_linv_batched_lower_f64(const double* L, const double* Linv_diag, const int32_t* n_points, int T, int N, double* Linv,
+                                 void* stream) {
+  if (T < 0 || N < 1) return SCAML_E_BADARG;
+  if (!L || !Linv_diag || !Linv) return SCAML_E_BADARG;
+  if (N > scaml_posterior_max_n()) return SCAML_E_TOOLARGE;
+  if (T == 0) return SCAML_OK;
+  Module& m = module();
+  hipError_t e = m.load();
+  if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
+  return launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream, 1);
 }
 
 static int posterior_linv_common(const double* Xq, const double* X, const double* theta, const double* Linv, const double* alpha,
@@ -656,7 +668,7 @@ int scaml_mll_backward_f64(const double* X, const double* theta, const double* L
     return SCAML_OK;
   }
   {
-    const int rc = launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);
+    const int rc = launch_linv(m, L, Linv_diag, n_points, T, N, Linv, stream);   // (dense: the 2 x 2 super-tiles of the tile kernel read zero blocks above the diagonal)
     if (rc != SCAML_OK) return rc;
   }
   {
@@ -733,10 +745,16 @@ int scaml_target_posterior_grad_f64(const double* cov_g, const double* mu_g, con
 // ---- (8) target GP: objective + gradient, and the whole L-BFGS refit, in one launch (csrc/gp_target_fit.hip) -------------
 namespace {
 constexpr int kTargetFitThreads = 512;
-size_t target_fit_lds_doubles(int n, int T, int D) {
-  const size_t nw = kTargetFitThreads / 64;
-  return (size_t)(n + 1) * (n + 2) / 2 + (size_t)n * (n + 1) / 2 + (size_t)n * D + 2 * (size_t)(n + 1) + 4 * (size_t)n + 2 * (size_t)T +
+int g_target_fit_path = getenv("SCAML_TARGET_FIT_NO_MFMA") ? 1 : 0;   // developer A/B switch: 0 by shape, 1 column-by-column elimination only
+size_t target_fit_lds_doubles(int n, int T, int D, bool mfma) {
+  const size_t nw = kTargetFitThreads / 64, nb = (size_t)(n + 15) / 16;
+  const size_t mats = mfma ? 2 * (nb * (nb + 1) / 2) * 16 * 17 : (size_t)(n + 1) * (n + 2) / 2 + (size_t)n * (n + 1) / 2;
+  return mats + (size_t)n * D + 2 * (size_t)(n + 1) + 4 * (size_t)n + 16 + 2 * (size_t)T +
          2 * (size_t)(D + 2) + D + nw * (scaml::TARGET_FIT_DMAX + 2) + nw + 8 + 2 * scaml::TARGET_FIT_HMAX;
+}
+// the matrix-core factorisation takes n <= 112 (two block triangles of 16 x 17 tiles in LDS)
+bool target_fit_use_mfma(int n, int T, int D) {
+  return g_target_fit_path == 0 && n <= 112 && target_fit_lds_doubles(n, T, D, true) * sizeof(double) <= 160 * 1024;
 }
 int target_spec_from_host(const double* spec, scaml::TargetSpec& sp) {
   sp.ls_lo = spec[0]; sp.ls_hi = spec[1]; sp.os_lo = spec[2]; sp.os_hi = spec[3]; sp.nz_lo = spec[4]; sp.nz_hi = spec[5];
@@ -760,7 +778,8 @@ int target_fit_launch(scaml::TargetFitParams& p, void* stream) {
   if (p.kind != SCAML_KIND_RBF && p.kind != SCAML_KIND_MATERN52) return SCAML_E_BADARG;
   if (!(p.s_all > 0.0)) return SCAML_E_BADARG;
   if (p.D > scaml::TARGET_FIT_DMAX) return SCAML_E_TOOLARGE;
-  const size_t lds = target_fit_lds_doubles(p.n, p.T, p.D) * sizeof(double);
+  p.use_mfma = target_fit_use_mfma(p.n, p.T, p.D) ? 1 : 0;
+  const size_t lds = target_fit_lds_doubles(p.n, p.T, p.D, p.use_mfma != 0) * sizeof(double);
   if (lds > 160 * 1024) return SCAML_E_TOOLARGE;
   if (p.B == 0) return SCAML_OK;
   Module& m = module();
@@ -779,7 +798,7 @@ int scaml_target_fit_max_d(void) { return scaml::TARGET_FIT_DMAX; }
 int scaml_target_fit_max_n(int T, int D) {
   if (T < 1 || D < 1 || D > scaml::TARGET_FIT_DMAX) return 0;
   int n = 0;
-  while (n < 4096 && target_fit_lds_doubles(n + 1, T, D) * sizeof(double) <= 160 * 1024) ++n;
+  while (n < 4096 && target_fit_lds_doubles(n + 1, T, D, false) * sizeof(double) <= 160 * 1024) ++n;
   return n;
 }
 
@@ -816,6 +835,14 @@ int scaml_target_fit_f64(const double* means_t, const double* covs_packed, const
   p.B = B; p.n = n; p.T = T; p.D = D; p.kind = kind; p.mode = 1; p.max_iter = max_iter; p.history = history; p.max_ls = 20;
   p.gtol = gtol; p.ftol = ftol;
   return target_fit_launch(p, stream);
+}
+
+// Developer switch: 1 keeps scaml_target_mll_f64 / scaml_target_fit_f64 on the column-by-column elimination where the matrix-core
+// factorisation would apply (A/B timing, testing one path against the other), 0 restores the choice by shape.  Returns the previous mode.
+int scaml_debug_target_fit_path(int mode) {
+  const int was = g_target_fit_path;
+  g_target_fit_path = mode == 1 ? 1 : 0;
+  return was;
 }
 
 // Developer switch: 1 routes scaml_mll_backward_f64 through the two-launch path (L^-1 in the workspace, then the K^-1 tile kernel)

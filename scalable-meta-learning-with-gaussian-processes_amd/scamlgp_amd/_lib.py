@@ -92,6 +92,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_posterior_cov_f64.argtypes = [_dp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, _dp, ctypes.c_uint, c_void_p]
     lib.scaml_linv_batched_f64.restype = c_int
     lib.scaml_linv_batched_f64.argtypes = [_dp, _dp, _dp, c_int, c_int, _dp, c_void_p]
+    lib.scaml_linv_batched_lower_f64.restype = c_int
+    lib.scaml_linv_batched_lower_f64.argtypes = [_dp, _dp, _dp, c_int, c_int, _dp, c_void_p]
     lib.scaml_posterior_linv_f64.restype = c_int
     lib.scaml_posterior_linv_f64.argtypes = [
         _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,  # Xq, X, theta, Linv, alpha, y_mean, y_std, n_points
@@ -133,6 +135,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_target_fit_f64.restype = c_int
     lib.scaml_target_fit_f64.argtypes = ([_dp] * 4 + [c_double, c_double, host_spec, _dp] + [c_int] * 7 + [c_double, c_double] + [_dp] * 5
                                          + [ctypes.c_longlong, c_void_p])
+    lib.scaml_debug_target_fit_path.restype = c_int
+    lib.scaml_debug_target_fit_path.argtypes = [c_int]
     lib.scaml_debug_force_two_launch_grad.restype = c_int
     lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib
@@ -157,6 +161,7 @@ EXPORTED_SYMBOLS = (
     "scaml_posterior_batched_f64",
     "scaml_posterior_cov_f64",
     "scaml_linv_batched_f64",
+    "scaml_linv_batched_lower_f64",
     "scaml_posterior_linv_f64",
     "scaml_cho_solve_batched_f64",
     "scaml_solve_lt_batched_f64",

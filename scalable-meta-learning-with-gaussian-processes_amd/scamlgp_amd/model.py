@@ -191,7 +191,8 @@ class SourceGPStack:
         ops.raise_if_not_psd(fit["info"])
         # the explicit inverse factor: computed once per fit, it makes every later posterior a matrix product
         # (the role of gpytorch's prediction-strategy caches; scamlgp/model.py:128, :281 query fixed source GPs)
-        fit["Linv"] = ops.linv_batched(fit["L"], fit["Linv_diag"], n_points=self.n_points)
+        # (only the block rows the posterior kernels read are written: lower_only)
+        fit["Linv"] = ops.linv_batched(fit["L"], fit["Linv_diag"], n_points=self.n_points, lower_only=True)
         self._fit = fit
         return fit
 

@@ -218,8 +218,10 @@ def _gp_fit_two_block(X, y, theta, kind, n_points, jitter, store_L, retry) -> Di
     return dict(L=L, alpha=alpha, quad=quad, logdet=logdet, mll=mll, info=info.to(torch.int32), jitter=jit, Linv_diag=linv)
 
 
-def linv_batched(L: torch.Tensor, Linv_diag: torch.Tensor, n_points: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """L^-1 (T, N, N) of the factors of a fused fit (zero above the diagonal).  scaml_linv_batched_f64."""
+def linv_batched(L: torch.Tensor, Linv_diag: torch.Tensor, n_points: Optional[torch.Tensor] = None, lower_only: bool = False) -> torch.Tensor:
+    """L^-1 (T, N, N) of the factors of a fused fit (zero above the diagonal).  scaml_linv_batched_f64; ``lower_only``:
+    scaml_linv_batched_lower_f64 -- the block rows above each strip's diagonal block are left unwritten (no kernel of the library
+    reads them; the result is then NOT a dense matrix to multiply with)."""
     T, N, _ = L.shape
     L = _check(L, "L", (T, N, N))
     Linv_diag = _check(Linv_diag, "Linv_diag", (T, (N + 15) // 16, 16, 16))
@@ -227,7 +229,8 @@ def linv_batched(L: torch.Tensor, Linv_diag: torch.Tensor, n_points: Optional[to
         n_points = _check(n_points, "n_points", (T,), torch.int32)
     out = torch.empty_like(L)
     with torch.cuda.device(L.device):
-        rc = _lib.lib.scaml_linv_batched_f64(_ptr(L), _ptr(Linv_diag), _ptr(n_points), T, N, _ptr(out), _stream_handle())
+        fn = _lib.lib.scaml_linv_batched_lower_f64 if lower_only else _lib.lib.scaml_linv_batched_f64
+        rc = fn(_ptr(L), _ptr(Linv_diag), _ptr(n_points), T, N, _ptr(out), _stream_handle())
     _lib.check_rc(rc, "scaml_linv_batched_f64")
     return out
 

@@ -36,7 +36,7 @@ extern "C" int emul_target_fit(const double* means_t, const double* covs_p, cons
     TfCtx c;
     c.tid = 0; c.nthr = 1; c.lane = 0; c.wave = 0; c.nwave = 1;
     c.n = n; c.T = T; c.D = D; c.P = P; c.E = n * (n + 1) / 2; c.kind = kind;
-    tf_carve(c, lds.data(), n, T, D, 1);
+    tf_carve(c, lds.data(), n, T, D, 1, 0);
     tf_main(c, p, b);
   }
   return 0;

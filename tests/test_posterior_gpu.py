@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import gp_oracle as O
-from scamlgp_amd import ops, synthetic
+from scamlgp_amd import _lib, ops, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -193,3 +193,29 @@ def test_fused_covariance_block_matches_unfused_and_oracle(T, N, D, M, Ma, kind,
         mu, cov = O.source_posterior(xt, X[t, :n], theta[t], kind, ref["L"], ref["alpha"], float(ym[t]), float(ysd[t]))
         torch.testing.assert_close(fused["mean"][t].cpu(), mu, rtol=RTOL, atol=RTOL * float(mu.abs().max()))
         torch.testing.assert_close(fused["cov"][t].cpu(), cov[:Ma], rtol=0, atol=RTOL * float(cov.abs().max()))
+
+
+def test_linv_lower_only_matches_the_dense_inverse_where_it_is_read(device):
+    """scaml_linv_batched_lower_f64 writes the block rows at or below each strip's diagonal block only: the lower triangle equals the
+    dense variant's bit for bit, the rest of the buffer is left as it was, and the posteriors computed from it are unchanged."""
+    T, N, D, kind = 3, 80, 3, O.KIND_MATERN52
+    g = torch.Generator().manual_seed(12)
+    X = torch.rand(T, N, D, dtype=torch.float64, generator=g).to(device)
+    y = torch.randn(T, N, dtype=torch.float64, generator=g).to(device)
+    theta = torch.tensor([[0.5] * D + [1.0, 1e-2]] * T, dtype=torch.float64, device=device)
+    fit = ops.gp_fit_fused(X, y, theta, kind, want_linv=True)
+    dense = ops.linv_batched(fit["L"], fit["Linv_diag"])
+    sentinel = 123.456
+    out = torch.full_like(dense, sentinel)
+    rc = _lib.lib.scaml_linv_batched_lower_f64(fit["L"].data_ptr(), fit["Linv_diag"].data_ptr(), None, T, N, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(torch.tril(out), torch.tril(dense))
+    blk = torch.arange(N, device=device) // 16
+    above = blk[:, None] < blk[None, :]          # block rows above the diagonal block of a column
+    assert bool((out[:, above] == sentinel).all())
+    xq = torch.rand(20, D, dtype=torch.float64, generator=g).to(device)
+    a = ops.source_posteriors(xq, X, theta, kind, fit["L"], fit["Linv_diag"], fit["alpha"], Linv=dense, cov_first=5)
+    b = ops.source_posteriors(xq, X, theta, kind, fit["L"], fit["Linv_diag"], fit["alpha"], Linv=out, cov_first=5)
+    for k in ("mean", "var", "cov"):   # (the pass adds its wave partials with LDS floating-point atomics: equal to the last bits, not bitwise)
+        torch.testing.assert_close(a[k], b[k], rtol=1e-12, atol=1e-14)

@@ -25,8 +25,17 @@ def test_spec_block_matches_reference_defaults(device):
     np.testing.assert_allclose(list(tp.spec_host), TARGET_SPEC)
 
 
-@pytest.mark.parametrize("n,T,D,kind", [(1, 3, 2, 0), (7, 3, 2, 1), (7, 32, 6, 1), (80, 3, 6, 0), (80, 32, 6, 1), (128, 5, 3, 1)])
-def test_objective_and_gradient_match_oracle_autograd(device, n, T, D, kind):
+@pytest.fixture(params=["matrix-core", "column-by-column"])
+def fit_path(request):
+    """Both factorisations of the kernel: blocked Cholesky on the matrix cores (n <= 112, the default there) and the column-by-column
+    elimination (n up to 128; forced through the developer switch for the shapes the matrix-core path would take)."""
+    was = _lib.lib.scaml_debug_target_fit_path(1 if request.param == "column-by-column" else 0)
+    yield request.param
+    _lib.lib.scaml_debug_target_fit_path(was)
+
+
+@pytest.mark.parametrize("n,T,D,kind", [(1, 3, 2, 0), (7, 3, 2, 1), (7, 32, 6, 1), (17, 4, 16, 0), (80, 3, 6, 0), (80, 32, 6, 1), (112, 6, 3, 1), (128, 5, 3, 1)])
+def test_objective_and_gradient_match_oracle_autograd(device, fit_path, n, T, D, kind):
     prob = make_target_problem(n, T, D, kind, seed=n + T, n_src=16)
     B = 3
     z = raw_start(D, T, seed=n, B=B)
@@ -39,7 +48,7 @@ def test_objective_and_gradient_match_oracle_autograd(device, n, T, D, kind):
         np.testing.assert_allclose(out["grad"][b].cpu().numpy(), g.numpy(), rtol=1e-4, atol=1e-7)
 
 
-def test_repeated_launches_are_bit_identical(device):
+def test_repeated_launches_are_bit_identical(device, fit_path):
     """Fixed-order reductions, no atomics: the optimiser's trajectory is reproducible."""
     prob = make_target_problem(40, 8, 4, 1, seed=2)
     tp = _problem_on_device(prob, device)
@@ -50,7 +59,7 @@ def test_repeated_launches_are_bit_identical(device):
         assert torch.equal(a["value"], b["value"]) and torch.equal(a["grad"], b["grad"])
 
 
-def test_jitter_ladder_and_hopeless_matrix(device):
+def test_jitter_ladder_and_hopeless_matrix(device, fit_path):
     """psd_safe_cholesky's ladder in-kernel: duplicated target points (singular kernel part) under a diagonal of 1e-8 noise minus
     6e-8 from the source term fail without jitter and with 1e-8 and pass with 1e-7; a NaN weight cannot be saved and comes back as
     NaN / info > 0 / zero gradient."""
@@ -78,7 +87,7 @@ def test_jitter_ladder_and_hopeless_matrix(device):
 
 
 @pytest.mark.parametrize("n,T,D,kind", [(12, 4, 2, 1), (80, 32, 6, 1)])
-def test_device_refit_reaches_scipy_optimum(device, n, T, D, kind):
+def test_device_refit_reaches_scipy_optimum(device, fit_path, n, T, D, kind):
     prob = make_target_problem(n, T, D, kind, seed=5, n_src=16)
     tp = _problem_on_device(prob, device)
     B = 3

@@ -13,6 +13,7 @@
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 80, T = argc > 2 ? atoi(argv[2]) : 32, D = argc > 3 ? atoi(argv[3]) : 6, kind = argc > 4 ? atoi(argv[4]) : 1;
   const int threads = argc > 5 ? atoi(argv[5]) : 512;
+  const int mfma = argc > 6 ? atoi(argv[6]) : 1;
   const int P = D + 2 + T, E = n * (n + 1) / 2, B = 1;
   std::vector<double> means((size_t)T * n), covs((size_t)T * E), X((size_t)n * D), y(n), z(P);
   srand(1);
@@ -42,8 +43,11 @@ int main(int argc, char** argv) {
   p.spec.w_lower = 1e-10;
   p.z = dz; p.value = dval; p.grad = dgrad; p.info = dinfo; p.jitter = djit; p.B = B; p.n = n; p.T = T; p.D = D; p.kind = kind; p.mode = 0; p.history = 1;
   const size_t nw = threads / 64;
-  const size_t lds = ((size_t)(n + 1) * (n + 2) / 2 + (size_t)n * (n + 1) / 2 + (size_t)n * D + 2 * (n + 1) + 4 * n + 2 * T + 2 * (D + 2) + D +
-                      nw * (scaml::TARGET_FIT_DMAX + 2) + nw + 8 + 2 * scaml::TARGET_FIT_HMAX) * 8;
+  const size_t nbk = (size_t)(n + 15) / 16;
+  const size_t mats = mfma ? 2 * (nbk * (nbk + 1) / 2) * 16 * 17 : (size_t)(n + 1) * (n + 2) / 2 + (size_t)n * (n + 1) / 2;
+  const size_t lds = (mats + (size_t)n * D + 2 * (n + 1) + 4 * n + 16 + 2 * T + 2 * (D + 2) + D + nw * (scaml::TARGET_FIT_DMAX + 2) + nw + 8 +
+                      2 * scaml::TARGET_FIT_HMAX) * 8;
+  p.use_mfma = mfma;
   CK(hipFuncSetAttribute((const void*)scaml::scaml_target_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -59,7 +63,7 @@ int main(int argc, char** argv) {
     int32_t info;
     CK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost)); CK(hipMemcpy(&val, dval, 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(&info, dinfo, 4, hipMemcpyDeviceToHost));
     const char* names[] = {"build", "eliminate", "scalars", "scale U + alpha", "K^-1 -> G", "grad w", "grad theta"};
-    printf("n=%d T=%d D=%d threads=%d: launch %.1f us, value %.6f info %d |", n, T, D, threads, ms * 1e3, val, info);
+    printf("n=%d T=%d D=%d threads=%d mfma=%d: launch %.1f us, value %.6f info %d |", n, T, D, threads, mfma, ms * 1e3, val, info);
     for (int i = 0; i < 7; ++i) printf(" %s %.1f", names[i], (st[i + 1] - st[i]) * 0.01);
     printf("\n");
   }
