@@ -68,3 +68,15 @@ elif which == "c5":
     acq = utils.UpperConfidenceBound(mdl, beta=9.0)
     us_score = timeit(lambda: acq(cand), reps=10)
     print(f"c5: T={T} N={N} D={D}: two-block source fit {us_fit:.1f} us; one UCB scoring pass over M={Mc} candidates with n={n} target points {us_score:.1f} us")
+    # round 3: the acquisition optimiser's evaluation with exact input gradients (R = 10 starts) and the on-device target refit
+    starts = torch.rand(10, D, dtype=torch.float64, generator=g)
+    us_vg = timeit(lambda: acq.value_and_grad(starts), reps=10)
+    prob = mdl.target_problem()
+    z0 = torch.cat([mdl.raw_theta, mdl.raw_weights]).unsqueeze(0).repeat(3, 1)
+    z0[1:, :D + 2] += 0.5
+    us_obj = timeit(lambda: ops.target_mll(prob, z0), reps=10)
+    import time as _t
+    ops.target_fit(prob, z0); torch.cuda.synchronize()
+    t0 = _t.perf_counter(); res = ops.target_fit(prob, z0); torch.cuda.synchronize(); ms_fit = (_t.perf_counter() - t0) * 1e3
+    print(f"c5: UCB value + exact input gradient at R=10 starts {us_vg:.1f} us; target objective + gradient (B=3, n={n}) {us_obj:.1f} us per launch; "
+          f"on-device refit of 3 starts {ms_fit:.2f} ms, stats {res['stats'].cpu().tolist()}")

@@ -3,7 +3,7 @@
 # posterior, configs[4] scoring pass), PMC passes per kernel, FETCH_SIZE / WRITE_SIZE calibration.
 # usage (via gpurun): bash tools/profile_round.sh r02        (outputs under gpurun_out/r02; copy the summaries to profiles/)
 set -e
-R=${1:-r02}
+R=${1:-r03}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -37,6 +37,7 @@ pmc fit gp_fit_fused bench.py --steps 20 --warmup 2 --no-cpu-baseline
 python3 tools/pmc_summary.py $OUT/pmc_fit gp_fit_fused --json $OUT/pmc_traffic.json > /dev/null || true
 pmc grad gp_mll_grad_fused bench.py --steps 10 --warmup 2 --no-cpu-baseline --step fit+grad
 pmc posterior gp_posterior_linv tools/prof_workloads.py posterior 4
+pmc c5 scaml_target_fit tools/prof_workloads.py c5 3
 python3 tools/pmc_summary.py $OUT/pmc_posterior gp_linv_kernel > $OUT/pmc_posterior_gp_linv_kernel.txt || true
 python3 tools/pmc_summary.py $OUT/pmc_posterior gp_posterior_kernel > $OUT/pmc_posterior_gp_posterior_kernel.txt || true
 # calibration of the two traffic counters for 8-byte and 16-byte per-lane streams (tools/fetch_calib.hip)
