@@ -8,19 +8,22 @@
 // Here one workgroup owns one start point (the warm start and every prior-sampled restart run side by side): the n x n matrix
 // lives in LDS, an evaluation is
 //   build      cov from the packed source covariances (coalesced over elements, sum over tasks), target kernel, noise, jitter
-//   eliminate  square-root-free Cholesky (A = L~ D^-1 L~^T, same pivots as LL^T) by columns; the right-hand side rides along as
-//              row n (its Schur complement is -quad) and the identity as n more right-hand sides, so ONE sweep with ONE barrier
-//              per column yields pivots, L^-1 y and L^-1 -- no separate triangular solves
-//   K^-1, alpha, G = (alpha alpha^T - K^-1) / 2 in place
+//   factorise  n <= 112: blocked Cholesky on the matrix cores -- 16 x 16 tiles in LDS, the diagonal tile factored and inverted by one
+//              wave in registers (pivots by v_readlane), panel / trailing update / L^-1 / K^-1 as v_mfma_f64_16x16x4 tile products
+//              (tf_factor_mfma);  112 < n <= 128 and the host-emulation build: square-root-free elimination by columns
+//              (A = L~ D^-1 L~^T, same pivots as LL^T), the right-hand side riding along as row n (its Schur complement is -quad)
+//              and the identity as n more right-hand sides, so ONE sweep with ONE barrier per column yields pivots, L^-1 y and L^-1
+//   K^-1, alpha, G = (alpha alpha^T - K^-1) / 2, packed
 //   gradient   d/dw_i = <G, 2 w_i C_i / s^2> + alpha . M_i / s   (one wave per task, coalesced over the packed elements)
 //              d/d(l, os, noise) from one pass over the kernel elements; chain rule through the sigmoid Interval, priors
-// and the optimiser (two-loop L-BFGS, projected backtracking line search on the box w >= w_lower, scipy L-BFGS-B's stopping
-// rules) runs in the same kernel on vectors in a small global workspace.  psd_safe_cholesky's jitter ladder (0, 1e-8, 1e-7,
-// 1e-6 on the diagonal) is applied per evaluation, in-kernel.
+// and the optimiser (two-loop L-BFGS, projected backtracking line search on the box w >= w_lower, curvature pairs in the free
+// subspace, scipy L-BFGS-B's stopping rules) runs in the same kernel on vectors in a small global workspace: the kernel body is one
+// loop around ONE inlined call of the evaluation (tf_run).  psd_safe_cholesky's jitter ladder (0, 1e-8, 1e-7, 1e-6 on the diagonal)
+// is applied per evaluation, in-kernel.
 //
-// Layout: packed lower triangle everywhere -- element (a, b), a >= b, at a (a + 1) / 2 + b.  Throughput is not the point of
-// this kernel (B <= a handful of workgroups on an otherwise idle chip); latency per evaluation is: plain fp64 VALU + LDS, no
-// matrix-core tiles (n <= 128, a 16-column panel would leave the serial pivot chain as it is).
+// Layout: packed lower triangle for everything the gradient phases touch -- element (a, b), a >= b, at a (a + 1) / 2 + b.
+// Throughput is not the point of this kernel (B <= a handful of workgroups on an otherwise idle chip); latency per evaluation is:
+// 101 us at n = 80, T = 32 (228 us through the column-by-column elimination; DESIGN.md 4d, profiles/r03_notes.md).
 //
 // SCAML_HOST_EMUL: the same source compiles as single-threaded host code (tests/host_emul: arithmetic of objective, gradient
 // and optimiser checked against the oracle on CPU; never part of libscaml_hip.so).
@@ -180,14 +183,24 @@ TF_DEV int tf_factor_mfma(const TfCtx& c, const TargetFitParams& p, double os, d
         double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
         const double* cp = p.covs_p + tf_idxL(a, b);
         int i = 0;
-        for (; i + 8 <= T; i += 8) {
-          double x[8];
+        for (; i + 16 <= T; i += 16) {   // sixteen task rows in flight: the pass is a chain of L2 round trips, not of bytes
+          double x[16];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = cp[(size_t)(i + j) * E];
-          acc += c.w2[i] * x[0] + c.w2[i + 4] * x[4];
-          acc1 += c.w2[i + 1] * x[1] + c.w2[i + 5] * x[5];
-          acc2 += c.w2[i + 2] * x[2] + c.w2[i + 6] * x[6];
-          acc3 += c.w2[i + 3] * x[3] + c.w2[i + 7] * x[7];
+          for (int j = 0; j < 16; ++j) x[j] = cp[(size_t)(i + j) * E];
+#pragma unroll
+          for (int j = 0; j < 16; j += 4) {
+            acc += c.w2[i + j] * x[j];
+            acc1 += c.w2[i + j + 1] * x[j + 1];
+            acc2 += c.w2[i + j + 2] * x[j + 2];
+            acc3 += c.w2[i + j + 3] * x[j + 3];
+          }
+        }
+        for (; i + 4 <= T; i += 4) {
+          const double x0 = cp[(size_t)i * E], x1 = cp[(size_t)(i + 1) * E], x2 = cp[(size_t)(i + 2) * E], x3 = cp[(size_t)(i + 3) * E];
+          acc += c.w2[i] * x0;
+          acc1 += c.w2[i + 1] * x1;
+          acc2 += c.w2[i + 2] * x2;
+          acc3 += c.w2[i + 3] * x3;
         }
         for (; i < T; ++i) acc += c.w2[i] * cp[(size_t)i * E];
         acc = (acc + acc1) + (acc2 + acc3);
@@ -356,7 +369,7 @@ TF_DEV int tf_factor_mfma(const TfCtx& c, const TargetFitParams& p, double os, d
   }
   TF_SYNC();
   TF_STAMP(3);
-  TF_STAMP(4);
+  TF_STAMP(4);   // (the column-by-column path's "scale U + alpha" phase has no counterpart here)
   // ---- K^-1 = X^T X by tiles, G = (alpha alpha^T - K^-1) / 2 (off-diagonal doubled) packed into the L region ----
   // (every L tile has been read for the last time before the barrier above)
   {
@@ -621,25 +634,38 @@ TF_DEV double tf_eval(const TfCtx& c, const TargetFitParams& p, const double* z,
   }   // (column-by-column path; the matrix-core path left G in Ap and alpha in place)
   const double inv_n = 1.0 / n;
   TF_STAMP(5);
-  // ---- d / d w_i: one wave per task ----
-  for (int i = c.wave; i < T; i += c.nwave) {
-    const double* cp = p.covs_p + (size_t)i * E;
-    const double* mp = p.means_t + (size_t)i * n;
-    double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0, accm = 0.0;
+  // ---- d / d w_i: one wave per task (two tasks per trip: eight coalesced loads in flight) ----
+  for (int i0 = 2 * c.wave; i0 < T; i0 += 2 * c.nwave) {
+    const int i1 = i0 + 1 < T ? i0 + 1 : i0;
+    const double* cp0 = p.covs_p + (size_t)i0 * E;
+    const double* cp1 = p.covs_p + (size_t)i1 * E;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     int e = c.lane;
-    for (; e + 3 * TF_LANES < E; e += 4 * TF_LANES) {   // four coalesced loads in flight per trip
-      const double x0 = cp[e], x1 = cp[e + TF_LANES], x2 = cp[e + 2 * TF_LANES], x3 = cp[e + 3 * TF_LANES];
-      acc += c.Ap[e] * x0;
-      acc1 += c.Ap[e + TF_LANES] * x1;
-      acc2 += c.Ap[e + 2 * TF_LANES] * x2;
-      acc3 += c.Ap[e + 3 * TF_LANES] * x3;
+    for (; e + 3 * TF_LANES < E; e += 4 * TF_LANES) {
+      const double x0 = cp0[e], x1 = cp0[e + TF_LANES], x2 = cp0[e + 2 * TF_LANES], x3 = cp0[e + 3 * TF_LANES];
+      const double y0 = cp1[e], y1 = cp1[e + TF_LANES], y2 = cp1[e + 2 * TF_LANES], y3 = cp1[e + 3 * TF_LANES];
+      const double g0 = c.Ap[e], g1 = c.Ap[e + TF_LANES], g2 = c.Ap[e + 2 * TF_LANES], g3 = c.Ap[e + 3 * TF_LANES];
+      a0 += g0 * x0; a1 += g1 * x1; a2 += g2 * x2; a3 += g3 * x3;
+      b0 += g0 * y0; b1 += g1 * y1; b2 += g2 * y2; b3 += g3 * y3;
     }
-    for (; e < E; e += TF_LANES) acc += c.Ap[e] * cp[e];
-    acc = (acc + acc1) + (acc2 + acc3);
-    for (int a = c.lane; a < n; a += TF_LANES) accm += c.alpha[a] * mp[a];
-    const double wi = c.w[i];
-    const double tot = tf_wave_sum(acc * (2.0 * wi * inv_s2) + accm * inv_s);
-    if (tf_last_lane(c)) gz[D + 2 + i] = (tot + tf_prior_dlogp(sp.w_prior, wi)) * inv_n;
+    for (; e < E; e += TF_LANES) {
+      const double g0 = c.Ap[e];
+      a0 += g0 * cp0[e];
+      b0 += g0 * cp1[e];
+    }
+    double am = 0.0, bm = 0.0;
+    for (int a = c.lane; a < n; a += TF_LANES) {
+      const double al = c.alpha[a];
+      am += al * p.means_t[(size_t)i0 * n + a];
+      bm += al * p.means_t[(size_t)i1 * n + a];
+    }
+    const double w0 = c.w[i0], w1 = c.w[i1];
+    const double t0 = tf_wave_sum(((a0 + a1) + (a2 + a3)) * (2.0 * w0 * inv_s2) + am * inv_s);
+    const double t1 = tf_wave_sum(((b0 + b1) + (b2 + b3)) * (2.0 * w1 * inv_s2) + bm * inv_s);
+    if (tf_last_lane(c)) {
+      gz[D + 2 + i0] = (t0 + tf_prior_dlogp(sp.w_prior, w0)) * inv_n;
+      if (i1 != i0) gz[D + 2 + i1] = (t1 + tf_prior_dlogp(sp.w_prior, w1)) * inv_n;
+    }
   }
   // ---- d / d (lengthscales, outputscale, noise) ----
   TF_STAMP(6);
