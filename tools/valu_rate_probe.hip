@@ -21,7 +21,7 @@
 #define S_MOV64(i)  "v_mov_b64 %" #i ", %16\n"
 #define S_CVTF32(i) "v_cvt_f32_f64 %1" #i ", %" #i "\n"
 template <int OP>
-__global__ void probe(double* out, long long* cyc, int iters) {
+__global__ __launch_bounds__(1024) void probe(double* out, long long* cyc, int iters) {
   double d[8]; float f[8];
   for (int i = 0; i < 8; ++i) { d[i] = 1.0 + threadIdx.x * 1e-3 + i; f[i] = 1.5f + i; }
   double c = 1.0000001, sc = 0.5;
@@ -71,7 +71,7 @@ void run(const char* name) {
   double* out; long long* cyc;
   CK(hipMalloc(&out, 1024 * sizeof(double))); CK(hipMalloc(&cyc, sizeof(long long)));
   const int iters = 2000;
-  for (int threads : {64, 256, 512}) {
+  for (int threads : {64, 256, 512, 1024}) {
     long long best = 1LL << 60;
     for (int rep = 0; rep < 3; ++rep) {
       hipLaunchKernelGGL(probe<OP>, dim3(1), dim3(threads), 0, 0, out, cyc, iters);
@@ -79,7 +79,7 @@ void run(const char* name) {
       long long h; CK(hipMemcpy(&h, cyc, sizeof(h), hipMemcpyDeviceToHost));
       if (h < best) best = h;
     }
-    printf("%-16s %3d threads (%d wave/SIMD): %6.2f ticks per instruction and wave\n", name, threads, threads <= 256 ? 1 : 2, (double)best / (iters * 8.0));
+    printf("%-16s %3d threads (%d wave/SIMD): %6.2f ticks per instruction and wave\n", name, threads, threads <= 256 ? 1 : threads / 256, (double)best / (iters * 8.0));
   }
   CK(hipFree(out)); CK(hipFree(cyc));
 }
