@@ -48,11 +48,13 @@ def _run_model(shard: bool):
     fwd = model.eval().forward(xq)
     th = torch.tensor([0.4, 0.6, 1.2, 2e-3], dtype=torch.float64)
     s_mll, s_grad = stack.summed_mll_and_grad(th)
+    pg = model.posterior_with_grad(xq)   # (sharded: one more fused all-reduce of the value + gradient columns)
     return dict(n_local=np.int64(stack.T), theta=stack.theta.cpu().numpy(), objective_sum=float(stack.last_fit_info["objective_sum"]),
                 m_all=float(model.m_all), s_all=float(model.s_all), source_means=model.source_means.cpu().numpy(),
                 source_covs=model.source_covs.cpu().numpy(), mll=float(model.mll()), mean=post.mvn.mean.cpu().numpy(),
                 var=post.mvn.variance.cpu().numpy(), cov=post.mvn.covariance_matrix.cpu().numpy(), fwd_mean=fwd.mean.cpu().numpy(),
-                fwd_cov=fwd.covariance_matrix.cpu().numpy(), s_mll=float(s_mll), s_grad=s_grad.cpu().numpy())
+                fwd_cov=fwd.covariance_matrix.cpu().numpy(), s_mll=float(s_mll), s_grad=s_grad.cpu().numpy(),
+                pg_mu=pg[0].cpu().numpy(), pg_var=pg[1].cpu().numpy(), pg_dmu=pg[2].cpu().numpy(), pg_dvar=pg[3].cpu().numpy())
 
 
 def _worker(rank, world, port, out_dir):
@@ -97,6 +99,11 @@ def test_sharded_model_matches_single_process(device, tmp_path):
         # configs[3]'s exchange step: [sum MLL || sum dMLL/dtheta] over all ranks' tasks
         np.testing.assert_allclose(g["s_mll"], ref["s_mll"], rtol=1e-11)
         np.testing.assert_allclose(g["s_grad"], ref["s_grad"], rtol=1e-9, atol=1e-12)
+        # the posterior with its input gradients: the shards' value / derivative columns add up to the unsharded model's
+        np.testing.assert_allclose(g["pg_mu"], ref["mean"], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(g["pg_var"], ref["var"], rtol=1e-6, atol=1e-10)
+        np.testing.assert_allclose(g["pg_dmu"], ref["pg_dmu"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(g["pg_dvar"], ref["pg_dvar"], rtol=1e-6, atol=1e-8)
 
 
 # ---- the target refit on a sharded model: every rank must end with the SAME weights and hyper-parameters -------------------
