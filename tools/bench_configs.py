@@ -82,3 +82,13 @@ us_score = timeit(lambda: acq(cand), reps=5, warm=2)
 print(f"C5 BO      T={T} N={N} D={D}: meta-fit of the source stack (2 starts x 30 L-BFGS iterations, all tasks batched) {t_fit:.2f} s; "
       f"ScaMLGP construction with n={n} target points {t_model * 1e3:.1f} ms; one UCB scoring pass over M={Mc} candidates "
       f"(all source posteriors + weighted prior + target posterior) {us_score / 1e3:.2f} ms", flush=True)
+# round 3: the rest of the BO step -- the acquisition optimiser's evaluation with exact gradients and the on-device refit
+starts = torch.rand(10, D, dtype=torch.float64, generator=g)
+us_vg = timeit(lambda: acq.value_and_grad(starts), reps=10, warm=2)
+t0 = time.perf_counter()
+utils.optimize_marginal_likelihood(mdl, 2)
+torch.cuda.synchronize()
+t_refit = time.perf_counter() - t0
+print(f"C5 BO      UCB value + exact input gradient at the R=10 starts of an L-BFGS-B evaluation {us_vg / 1e3:.2f} ms (eager; central differences "
+      f"score 130 points); refit of the target GP (weights + hyper-parameters, warm start + 2 restarts, one launch on the device) "
+      f"{t_refit * 1e3:.1f} ms, stats {mdl.last_fit_info['stats'].cpu().tolist()}", flush=True)
