@@ -61,6 +61,7 @@ struct TfCtx {
   // matrix-core path (n <= 112): 16 x 16 tiles at pitch 17, lower block triangle, tile (i, j) at (i (i + 1) / 2 + j) * TF_TS
   double *Lt, *Xt;
   int nb, mfma;
+  int solo;   // optimiser bookkeeping by ONE wave (P <= 64: a lane per variable): reductions stay in the wave, barriers are no-ops
 };
 constexpr int TF_TP = 17, TF_TS = 16 * TF_TP;
 
@@ -86,9 +87,16 @@ TF_DEV double tf_wave_sum(double x) {
 }
 TF_DEV bool tf_last_lane(const TfCtx& c) { return c.lane == TF_LANES - 1; }
 
-// sum over the workgroup, result in every thread (fixed order: deterministic).  Two barriers.
+// barrier of the optimiser's bookkeeping: a real one, or nothing when a single wave does the work (its own program order is enough:
+// a lane only ever touches its own vector component, dot products travel through the wave reduction)
+#define TF_OSYNC(c) do { if (!(c).solo) TF_SYNC(); } while (0)
+
+// sum over the workgroup, result in every thread (fixed order: deterministic).  Two barriers (none in solo mode).
 TF_DEV double tf_block_sum(const TfCtx& c, double x) {
   const double s = tf_wave_sum(x);
+#ifndef SCAML_HOST_EMUL
+  if (c.solo) return readlane_f64(s, 63);
+#endif
   if (tf_last_lane(c)) c.red[c.wave] = s;
   TF_SYNC();
   double t = 0.0;
@@ -97,9 +105,10 @@ TF_DEV double tf_block_sum(const TfCtx& c, double x) {
   return t;
 }
 TF_DEV double tf_block_max(const TfCtx& c, double x) {
-  // (max needs no order; reuse the sum path: waves publish their lanes' maxima through LDS)
+  // (max needs no order; waves publish their lanes' maxima through LDS)
 #ifndef SCAML_HOST_EMUL
   for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+  if (c.solo) return x;
 #endif
   if (c.lane == 0) c.red[c.wave] = x;
   TF_SYNC();
@@ -767,6 +776,16 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
     for (int i = D + 2 + c.tid; i < P; i += c.nthr) x[i] = fmax(x[i], lb);
     TF_SYNC();
   }
+  TfCtx o = c;   // who does the vector bookkeeping between evaluations
+#ifndef SCAML_HOST_EMUL
+  if (P <= TF_LANES) {
+    o.solo = 1;
+    o.tid = c.lane;
+    o.nthr = TF_LANES;
+    o.wave = 0;
+    o.nwave = 1;
+  }
+#endif
   double f = 0.0, t = 1.0, gd = 0.0;
   int n_eval = 0, it = 0, status = 0, hist = 0, head = 0, ls = 0;   // status 0 max_iter, 1 converged (gradient), 2 converged (decrease), 3 line search failed, 4 bad start
   for (;;) {
@@ -785,142 +804,148 @@ TF_DEV void tf_run(const TfCtx& c, const TargetFitParams& p, int prob) {
       }
       return;
     }
-    bool go_final = false, new_dir = false;
-    if (state == INIT) {
-      f = -val;
-      for (int i = c.tid; i < P; i += c.nthr) g[i] = -g[i];
-      TF_SYNC();
-      if (!tf_finite(f)) {
-        status = 4;
-        go_final = true;
-      } else if (p.max_iter < 1) {
-        go_final = true;
-      } else {
-        new_dir = true;
-      }
-    } else {   // TRIAL: xn, gn hold the trial point and +d mll / dz there
-      const double fn = -val;
-      double dec = 0.0;
-      for (int i = c.tid; i < P; i += c.nthr) dec += g[i] * (xn[i] - x[i]);
-      dec = tf_block_sum(c, dec);
-      if (tf_finite(fn) && fn <= f + c1 * dec) {
-        // curvature pair, then the step
-        double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
-        const int slot = head;
-        // (the pair lives in the subspace of the variables that were free in this step and still are: a weight that sat on, or
-        //  ran into, the bound contributes a projected step and a gradient change that say nothing about the curvature there)
-        for (int i = c.tid; i < P; i += c.nthr) {
-          const double gi = -gn[i];
-          const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
-          const double sv = fr ? xn[i] - x[i] : 0.0, yv = fr ? gi - g[i] : 0.0;
-          sy += sv * yv;
-          ss += sv * sv;
-          yy += yv * yv;
-        }
-        sy = tf_block_sum(c, sy);
-        ss = tf_block_sum(c, ss);
-        yy = tf_block_sum(c, yy);
-        const bool push = sy > 1e-10 * sqrt(ss) * sqrt(yy);
-        for (int i = c.tid; i < P; i += c.nthr) {
-          const double gi = -gn[i];
-          if (push) {
-            const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
-            S[(size_t)slot * P + i] = fr ? xn[i] - x[i] : 0.0;
-            Y[(size_t)slot * P + i] = fr ? gi - g[i] : 0.0;
-          }
-          x[i] = xn[i];
-          g[i] = gi;
-          // projected gradient (scipy's pgtol test): |P(x - g) - x|
-          double st = x[i] - gi;
-          if (i >= D + 2) st = fmax(st, lb);
-          pg = fmax(pg, fabs(st - x[i]));
-        }
-        if (push) {
-          if (c.tid == 0) rho[slot] = 1.0 / sy;
-          head = (head + 1) % H;
-          if (hist < H) ++hist;
-        }
-        pg = tf_block_max(c, pg);
-        const double rel = (f - fn) / fmax(fmax(fabs(f), fabs(fn)), 1.0);
-        f = fn;
-        if (pg <= p.gtol) { status = 1; go_final = true; }
-        else if (rel <= p.ftol && it > 1) { status = 2; go_final = true; }
-        else if (it >= p.max_iter) { go_final = true; }
-        else new_dir = true;
-      } else {
-        // backtrack: the minimiser of the parabola through f, its slope along the projected step, and the trial value -- kept inside
-        // [0.1 t, 0.5 t]; a trial that is not finite just halves
-        double tn = 0.5 * t;
-        if (tf_finite(fn) && dec < 0.0) {
-          const double tq = -0.5 * dec * t / (fn - f - dec);   // slope along the step = dec / t
-          if (tq > 0.1 * t && tq < 0.5 * t) tn = tq;
-          else if (tq <= 0.1 * t) tn = 0.1 * t;
-        }
-        t = tn;
-        if (++ls >= p.max_ls) { status = 3; go_final = true; }
-      }
-    }
-    if (new_dir) {
-      ++it;
-      ls = 0;
-      // free variables: everything except weights sitting on the bound whose gradient pushes outwards
-      for (int i = c.tid; i < P; i += c.nthr) {
-        const bool fixed = i >= D + 2 && x[i] <= lb && g[i] > 0.0;
-        mask[i] = fixed ? 0.0 : 1.0;
-        q[i] = fixed ? 0.0 : g[i];
-      }
-      TF_SYNC();
-      // two-loop recursion, newest pair first (pair h lives in slot (head - 1 - h) mod H)
-      for (int h = 0; h < hist; ++h) {
-        const int slot = (head - 1 - h + 2 * H) % H;
-        const double a = rho[slot] * tf_dot(c, S + (size_t)slot * P, q);
-        if (c.tid == 0) al[slot] = a;
-        for (int i = c.tid; i < P; i += c.nthr) q[i] -= a * Y[(size_t)slot * P + i];
-        TF_SYNC();
-      }
-      double gamma = 1.0;
-      if (hist > 0) {
-        const int slot = (head - 1 + H) % H;
-        const double yy = tf_dot(c, Y + (size_t)slot * P, Y + (size_t)slot * P);
-        if (yy > 0.0) gamma = 1.0 / (rho[slot] * yy);
-      }
-      for (int i = c.tid; i < P; i += c.nthr) q[i] *= gamma;
-      TF_SYNC();
-      for (int h = hist - 1; h >= 0; --h) {
-        const int slot = (head - 1 - h + 2 * H) % H;
-        const double b = rho[slot] * tf_dot(c, Y + (size_t)slot * P, q);
-        const double a = al[slot];
-        for (int i = c.tid; i < P; i += c.nthr) q[i] += (a - b) * S[(size_t)slot * P + i];
-        TF_SYNC();
-      }
-      for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -q[i] * mask[i];
-      TF_SYNC();
-      gd = tf_dot(c, g, dvec);
-      t = 1.0;
-      if (!(gd < 0.0) || hist == 0) {   // first step / not a descent direction: steepest descent, scipy-like first step length
-        for (int i = c.tid; i < P; i += c.nthr) dvec[i] = -g[i] * mask[i];
-        TF_SYNC();
-        gd = tf_dot(c, g, dvec);
-        t = fmin(1.0, 1.0 / sqrt(fmax(-gd, 1e-24)));
-        if (!(gd < 0.0)) {   // the projected gradient is zero: converged
-          status = 1;
+    // ---- the optimiser's bookkeeping: by every thread, or -- P <= 64, a lane per variable -- by wave 0 alone, with no barrier and
+    //      every dot product a wave reduction (45 us per iteration of vector operations through barriers became ~5) ----
+    if (!o.solo || c.wave == 0) {
+      bool go_final = false, new_dir = false;
+      if (state == INIT) {
+        f = -val;
+        for (int i = o.tid; i < P; i += o.nthr) g[i] = -g[i];
+        TF_OSYNC(o);
+        if (!tf_finite(f)) {
+          status = 4;
           go_final = true;
+        } else if (p.max_iter < 1) {
+          go_final = true;
+        } else {
+          new_dir = true;
+        }
+      } else {   // TRIAL: xn, gn hold the trial point and +d mll / dz there
+        const double fn = -val;
+        double dec = 0.0;
+        for (int i = o.tid; i < P; i += o.nthr) dec += g[i] * (xn[i] - x[i]);
+        dec = tf_block_sum(o, dec);
+        if (tf_finite(fn) && fn <= f + c1 * dec) {
+          // curvature pair, then the step
+          double sy = 0.0, ss = 0.0, yy = 0.0, pg = 0.0;
+          const int slot = head;
+          // (the pair lives in the subspace of the variables that were free in this step and still are: a weight that sat on, or
+          //  ran into, the bound contributes a projected step and a gradient change that say nothing about the curvature there)
+          for (int i = o.tid; i < P; i += o.nthr) {
+            const double gi = -gn[i];
+            const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
+            const double sv = fr ? xn[i] - x[i] : 0.0, yv = fr ? gi - g[i] : 0.0;
+            sy += sv * yv;
+            ss += sv * sv;
+            yy += yv * yv;
+          }
+          sy = tf_block_sum(o, sy);
+          ss = tf_block_sum(o, ss);
+          yy = tf_block_sum(o, yy);
+          const bool push = sy > 1e-10 * sqrt(ss) * sqrt(yy);
+          for (int i = o.tid; i < P; i += o.nthr) {
+            const double gi = -gn[i];
+            if (push) {
+              const bool fr = mask[i] != 0.0 && !(i >= D + 2 && xn[i] <= lb);
+              S[(size_t)slot * P + i] = fr ? xn[i] - x[i] : 0.0;
+              Y[(size_t)slot * P + i] = fr ? gi - g[i] : 0.0;
+            }
+            x[i] = xn[i];
+            g[i] = gi;
+            // projected gradient (scipy's pgtol test): |P(x - g) - x|
+            double st = x[i] - gi;
+            if (i >= D + 2) st = fmax(st, lb);
+            pg = fmax(pg, fabs(st - x[i]));
+          }
+          if (push) {
+            if (o.tid == 0) rho[slot] = 1.0 / sy;
+            head = (head + 1) % H;
+            if (hist < H) ++hist;
+          }
+          pg = tf_block_max(o, pg);
+          const double rel = (f - fn) / fmax(fmax(fabs(f), fabs(fn)), 1.0);
+          f = fn;
+          if (pg <= p.gtol) { status = 1; go_final = true; }
+          else if (rel <= p.ftol && it > 1) { status = 2; go_final = true; }
+          else if (it >= p.max_iter) { go_final = true; }
+          else new_dir = true;
+        } else {
+          // backtrack: the minimiser of the parabola through f, its slope along the projected step, and the trial value -- kept inside
+          // [0.1 t, 0.5 t]; a trial that is not finite just halves
+          double tn = 0.5 * t;
+          if (tf_finite(fn) && dec < 0.0) {
+            const double tq = -0.5 * dec * t / (fn - f - dec);   // slope along the step = dec / t
+            if (tq > 0.1 * t && tq < 0.5 * t) tn = tq;
+            else if (tq <= 0.1 * t) tn = 0.1 * t;
+          }
+          t = tn;
+          if (++ls >= p.max_ls) { status = 3; go_final = true; }
         }
       }
+      if (new_dir) {
+        ++it;
+        ls = 0;
+        // free variables: everything except weights sitting on the bound whose gradient pushes outwards
+        for (int i = o.tid; i < P; i += o.nthr) {
+          const bool fixed = i >= D + 2 && x[i] <= lb && g[i] > 0.0;
+          mask[i] = fixed ? 0.0 : 1.0;
+          q[i] = fixed ? 0.0 : g[i];
+        }
+        TF_OSYNC(o);
+        // two-loop recursion, newest pair first (pair h lives in slot (head - 1 - h) mod H)
+        for (int h = 0; h < hist; ++h) {
+          const int slot = (head - 1 - h + 2 * H) % H;
+          const double a = rho[slot] * tf_dot(o, S + (size_t)slot * P, q);
+          if (o.tid == 0) al[slot] = a;
+          for (int i = o.tid; i < P; i += o.nthr) q[i] -= a * Y[(size_t)slot * P + i];
+          TF_OSYNC(o);
+        }
+        double gamma = 1.0;
+        if (hist > 0) {
+          const int slot = (head - 1 + H) % H;
+          const double yy = tf_dot(o, Y + (size_t)slot * P, Y + (size_t)slot * P);
+          if (yy > 0.0) gamma = 1.0 / (rho[slot] * yy);
+        }
+        for (int i = o.tid; i < P; i += o.nthr) q[i] *= gamma;
+        TF_OSYNC(o);
+        for (int h = hist - 1; h >= 0; --h) {
+          const int slot = (head - 1 - h + 2 * H) % H;
+          const double b = rho[slot] * tf_dot(o, Y + (size_t)slot * P, q);
+          const double a = al[slot];
+          for (int i = o.tid; i < P; i += o.nthr) q[i] += (a - b) * S[(size_t)slot * P + i];
+          TF_OSYNC(o);
+        }
+        for (int i = o.tid; i < P; i += o.nthr) dvec[i] = -q[i] * mask[i];
+        TF_OSYNC(o);
+        gd = tf_dot(o, g, dvec);
+        t = 1.0;
+        if (!(gd < 0.0) || hist == 0) {   // first step / not a descent direction: steepest descent, scipy-like first step length
+          for (int i = o.tid; i < P; i += o.nthr) dvec[i] = -g[i] * mask[i];
+          TF_OSYNC(o);
+          gd = tf_dot(o, g, dvec);
+          t = fmin(1.0, 1.0 / sqrt(fmax(-gd, 1e-24)));
+          if (!(gd < 0.0)) {   // the projected gradient is zero: converged
+            status = 1;
+            go_final = true;
+          }
+        }
+      }
+      if (!go_final) {   // next trial point on the projected ray
+        for (int i = o.tid; i < P; i += o.nthr) {
+          double v = x[i] + t * dvec[i];
+          if (i >= D + 2) v = fmax(v, lb);
+          xn[i] = v;
+        }
+      }
+      if (o.tid == 0) c.sc[1] = go_final ? (double)FINAL : (double)TRIAL;
     }
-    if (go_final) {
+    TF_SYNC();
+    if ((int)c.sc[1] == FINAL) {
       state = FINAL;
       zc = x;
       gout = nullptr;
       continue;
     }
-    // next trial point on the projected ray
-    for (int i = c.tid; i < P; i += c.nthr) {
-      double v = x[i] + t * dvec[i];
-      if (i >= D + 2) v = fmax(v, lb);
-      xn[i] = v;
-    }
-    TF_SYNC();
     state = TRIAL;
     zc = xn;
     gout = gn;
@@ -978,6 +1003,7 @@ extern "C" __global__ __launch_bounds__(TF_MAX_THREADS) void scaml_target_fit_ke
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: every row index derived from it is SALU work, off the vector unit)
   c.nwave = blockDim.x >> 6;
   c.n = p.n; c.T = p.T; c.D = p.D; c.P = p.D + 2 + p.T; c.E = p.n * (p.n + 1) / 2; c.kind = p.kind;
+  c.solo = 0;
   tf_carve(c, tf_lds, p.n, p.T, p.D, c.nwave, p.use_mfma);
   tf_main(c, p, blockIdx.x);
 }

@@ -34,7 +34,7 @@ extern "C" int emul_target_fit(const double* means_t, const double* covs_p, cons
   std::vector<double> lds((size_t)(n + 1) * (n + 2) + n * D + 8 * n + 2 * T + 3 * D + 200);
   for (int b = 0; b < B; ++b) {
     TfCtx c;
-    c.tid = 0; c.nthr = 1; c.lane = 0; c.wave = 0; c.nwave = 1;
+    c.tid = 0; c.nthr = 1; c.lane = 0; c.wave = 0; c.nwave = 1; c.solo = 0;
     c.n = n; c.T = T; c.D = D; c.P = P; c.E = n * (n + 1) / 2; c.kind = kind;
     tf_carve(c, lds.data(), n, T, D, 1, 0);
     tf_main(c, p, b);
