@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
   extern __shared__ double lds[];
   const int N = p.N, NB = (N + 15) / 16, NP = NB * 16;
   const int task = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = SCAML_WAVE_INDEX(tid), nwaves = blockDim.x >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void gp_cho_solve_kernel(ChoSolveParams p) {
   extern __shared__ double lds[];
   const int N = p.N, R = p.R, NB = (N + 15) / 16, NP = NB * 16;
   const int task = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = SCAML_WAVE_INDEX(tid), nwaves = blockDim.x >> 6;
   const int lc = lane & 15, lq = lane >> 4;
   int n = p.n_points ? p.n_points[task] : N;
   n = n < 0 ? 0 : (n > N ? N : n);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   const int task = (slot / groups) * 8 + xcd;
   const int group = slot % groups;
   if (task >= p.T) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = SCAML_WAVE_INDEX(tid);
   const int lc = lane & 15, lq = lane >> 4;
   exp2_table_init(exptab, tid);
   if (tid < D && tid < 64) invl_s[tid] = 1.0 / p.theta[(size_t)task * (D + 2) + tid];

@@ -9,6 +9,15 @@
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// The wave's index inside its workgroup as a SCALAR: tid >> 6 is the same in all 64 lanes, but the compiler cannot know, and every
+// block-row / strip index derived from it is then vector arithmetic -- on a SIMD that its waves' VALU instructions already contend
+// for (profiles/r03_probe_valu_overlap.txt).  Through readfirstlane that arithmetic moves to the scalar unit.
+#ifdef SCAML_VECTOR_WAVE   // (A/B: the plain expression)
+#define SCAML_WAVE_INDEX(tid) ((tid) >> 6)
+#else
+#define SCAML_WAVE_INDEX(tid) __builtin_amdgcn_readfirstlane((tid) >> 6)
+#endif
+
 namespace scaml {
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
