@@ -238,13 +238,13 @@ class SourceGPStack:
         return sdist.reduce_mll_and_grad(mll.detach(), g, self.shard)
 
     # -- posteriors -----------------------------------------------------------------------
-    def posterior(self, xq: torch.Tensor, cov_first: int = 0, want_var: bool = True) -> dict:
+    def posterior(self, xq: torch.Tensor, cov_first: int = 0, want_var: bool = True, VA: Optional[torch.Tensor] = None) -> dict:
         """Un-standardised posteriors of all tasks at xq (M, D): mean (T, M), var (T, M),
-        cov (T, cov_first, M)."""
+        cov (T, cov_first, M).  ``VA``: the cached V of the leading ``cov_first`` points (ops.source_posteriors)."""
         f = self.fit
         return ops.source_posteriors(xq.to(self.device, torch.float64), self.X, self.theta, self.kind, f["L"], f["Linv_diag"],
                                      f["alpha"], self.y_mean, self.y_std, n_points=self.n_points, want_var=want_var,
-                                     cov_first=cov_first, Linv=f.get("Linv"))
+                                     cov_first=cov_first, Linv=f.get("Linv"), VA=VA)
 
     def raw_targets(self) -> torch.Tensor:
         """All source observations in original units, concatenated (scamlgp/model.py:264-270)."""
@@ -592,12 +592,14 @@ class ScaMLGP:
         self._active_cache = (held, w_full, active)
         return w_full, active
 
-    def _source_prior(self, x: torch.Tensor, cov_first: int):
+    def _source_prior(self, x: torch.Tensor, cov_first: int, train_first: bool = False):
         """sum_i w_i mu_i(x) (M,), sum_i w_i^2 Sigma_i (cov_first, M), sum_i w_i^2 var_i (M,) over the significant tasks
         of ALL ranks, in original units: one batched posterior launch over this rank's stack, the weighted task sums,
         and -- sharded -- ONE all-reduce of the fused buffer [mu_s || Sigma_s || var_s]."""
         w_full, active = self._active_tasks()
-        p = self._stack.posterior(x, cov_first=cov_first)
+        # (the leading points of a joint evaluation are the model's training inputs: their V is computed once per model)
+        va = self._train_VA() if (train_first and 0 < cov_first == self.n <= 96 and x.shape[0] > self.n and self._stack.fit.get("Linv") is not None) else None
+        p = self._stack.posterior(x, cov_first=cov_first, VA=va)
         mu_s, cov_s = ops.weighted_prior_reduce(p["mean"], p["cov"], w_full, active)
         var_s = ops.weighted_task_sum(p["var"], w_full, 2, active)
         mu_s, cov_s, var_s = sdist.fused_allreduce([mu_s, cov_s, var_s], self._shard)
@@ -747,7 +749,7 @@ class ScaMLGP:
             # the library's target-GP path: weighted source sums at cat(train_X, Xq), then assemble -> jittered Cholesky
             # (T = 1) -> solve -> finish: four launches, no host synchronisation, no torch arithmetic
             xall = torch.cat([self.train_X, Xq], 0)
-            mu_s, cov_s, var_s = self._source_prior(xall, n)
+            mu_s, cov_s, var_s = self._source_prior(xall, n, train_first=True)
             mu_o, var_o, info, _ = ops.target_posterior(cov_s, mu_s, var_s, xall, self.theta, self.train_targets, self._m_all_f,
                                                          self._s_all_f, self.kind, observation_noise)
             # (a factorisation that fails even with jitter -- psd_safe_cholesky would raise NotPSDError -- comes back as NaN: the status

@@ -323,12 +323,15 @@ def source_posteriors(
     keep_V: bool = False,
     mean_only: bool = False,
     Linv: Optional[torch.Tensor] = None,
+    VA: Optional[torch.Tensor] = None,
 ) -> Dict[str, torch.Tensor]:
     """Posteriors of all source GPs at the shared query points Xq (M, D), or at per-task query sets
     Xq (T, M, D).  ``mean_only`` skips the triangular solve (mu = m + s K_* alpha only; L and
     Linv_diag may be None); ``keep_V`` also returns V = L^-1 K_*^T (T, N, M).  With ``Linv`` (T, N, N) from
     ``linv_batched`` the posteriors come from the explicit inverse factor (scaml_posterior_linv_f64: a
     triangular matrix product instead of a substitution -- the fast path when one fit serves many queries).
+    ``VA`` (T, N, cov_first): the V of the leading ``cov_first`` query points from an earlier call (``keep_V=True`` on those points
+    alone) -- the fused covariance pass then skips recomputing it (the leading points are a model's fixed training inputs).
 
     Returns dict(mean (T, M), var (T, M) or None, cov (T, cov_first, M) or None): ``cov`` is the
     posterior covariance between the first ``cov_first`` query points and all of them (put the
@@ -375,13 +378,16 @@ def source_posteriors(
             # the covariance block comes out of the posterior pass itself: V of the leading cov_first points first
             # (T, N, cov_first -- small), then one pass over all M points gives mean, var and cov; V (T, N, M) is never stored
             Linv = _check(Linv, "Linv", (T, N, N))
-            Xa = Xq[:, :cov_first].contiguous() if Xq.dim() == 3 else Xq[:cov_first].contiguous()
-            VA = torch.empty((T, N, cov_first), dtype=torch.float64, device=dev)
-            mu_a = torch.empty((T, cov_first), dtype=torch.float64, device=dev)
-            rc = _lib.lib.scaml_posterior_linv_f64(
-                _ptr(Xa), _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean), _ptr(y_std), _ptr(n_points),
-                T, N, cov_first, D, int(kind), _ptr(mu_a), None, _ptr(VA), flags, _stream_handle())
-            _lib.check_rc(rc, "scaml_posterior_linv_f64")
+            if VA is not None:
+                VA = _check(VA, "VA", (T, N, cov_first))
+            else:
+                Xa = Xq[:, :cov_first].contiguous() if Xq.dim() == 3 else Xq[:cov_first].contiguous()
+                VA = torch.empty((T, N, cov_first), dtype=torch.float64, device=dev)
+                mu_a = torch.empty((T, cov_first), dtype=torch.float64, device=dev)
+                rc = _lib.lib.scaml_posterior_linv_f64(
+                    _ptr(Xa), _ptr(X), _ptr(theta), _ptr(Linv), _ptr(alpha), _ptr(y_mean), _ptr(y_std), _ptr(n_points),
+                    T, N, cov_first, D, int(kind), _ptr(mu_a), None, _ptr(VA), flags, _stream_handle())
+                _lib.check_rc(rc, "scaml_posterior_linv_f64")
             cov = torch.empty((T, cov_first, M), dtype=torch.float64, device=dev)
             if var is None:
                 var = torch.empty((T, M), dtype=torch.float64, device=dev)
