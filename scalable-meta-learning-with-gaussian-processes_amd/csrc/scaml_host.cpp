@@ -737,7 +737,8 @@ int scaml_target_posterior_grad_f64(const double* cov_g, const double* mu_g, con
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   void* args[] = {(void*)&cov_g, (void*)&mu_g, (void*)&var_g, (void*)&Xt, (void*)&Xq, (void*)&theta, (void*)&alpha, (void*)&Z, (void*)&s_all,
                   (void*)&info, (void*)&n, (void*)&Mq, (void*)&D, (void*)&dmu, (void*)&dvar};
-  e = hipModuleLaunchKernel(m.tgt_grad[kind], (unsigned)((Mq * D + 63) / 64), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr);
+  if (D > 15) return SCAML_E_TOOLARGE;
+  e = hipModuleLaunchKernel(m.tgt_grad[kind], (unsigned)Mq, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr);   // one wave per query point
   if (e != hipSuccess) { set_error("hipModuleLaunchKernel(target_grad)", e); return SCAML_E_LAUNCH; }
   return SCAML_OK;
 }
