@@ -706,6 +706,18 @@ class ScaMLGP:
             self._train_prior_cache = c
         return c[1]
 
+    def _target_factor(self):
+        """The jittered Cholesky of the target GP's training block Knn (+ alpha) at the current weights / hyper-parameters, or None
+        if it has not been computed for this parameter state yet: it does not depend on the query points, and an acquisition
+        optimisation scores hundreds of query batches against one parameter state."""
+        c = getattr(self, "_factor_cache", None)
+        now = (self.weights,) + self._param_tensors()
+        return c[1] if c is not None and self._same_tensors(c[0], now) else None
+
+    def _keep_target_factor(self, factor) -> None:
+        now = (self.weights,) + self._param_tensors()
+        self._factor_cache = (tuple((t, t._version) for t in now), factor)
+
     def posterior_with_grad(self, X: torch.Tensor):
         """Target posterior mean / variance at X (Mq, D) in original units AND their gradients w.r.t. X: (mu (Mq,), var (Mq,),
         dmu (Mq, D), dvar (Mq, D)).  The reference gets these from torch autograd through ``model.posterior`` inside botorch's
@@ -732,7 +744,9 @@ class ScaMLGP:
         var_s = torch.cat([var_t, var_g.reshape(Mq, 16)[:, 0]])
         xall = torch.cat([self.train_X, Xq], 0)
         theta = self.theta
-        full = ops.target_posterior_full(cov_s, mean_s, var_s, xall, theta, self.train_targets, self._m_all_f, self._s_all_f, self.kind)
+        full = ops.target_posterior_full(cov_s, mean_s, var_s, xall, theta, self.train_targets, self._m_all_f, self._s_all_f, self.kind,
+                                         factor=self._target_factor())
+        self._keep_target_factor(full["factor"])
         dmu, dvar = ops.target_posterior_grad(cov_g, mu_g, var_g, self.train_X, Xq, theta, full["alpha"], full["Z"], self._s_all_f,
                                               full["info"], self.kind)
         return full["mu"], full["var"], dmu, dvar
@@ -750,8 +764,10 @@ class ScaMLGP:
             # (T = 1) -> solve -> finish: four launches, no host synchronisation, no torch arithmetic
             xall = torch.cat([self.train_X, Xq], 0)
             mu_s, cov_s, var_s = self._source_prior(xall, n, train_first=True)
-            mu_o, var_o, info, _ = ops.target_posterior(cov_s, mu_s, var_s, xall, self.theta, self.train_targets, self._m_all_f,
-                                                         self._s_all_f, self.kind, observation_noise)
+            full = ops.target_posterior_full(cov_s, mu_s, var_s, xall, self.theta, self.train_targets, self._m_all_f, self._s_all_f, self.kind,
+                                             observation_noise, factor=self._target_factor())
+            self._keep_target_factor(full["factor"])
+            mu_o, var_o = full["mu"], full["var"]
             # (a factorisation that fails even with jitter -- psd_safe_cholesky would raise NotPSDError -- comes back as NaN: the status
             #  stays on the device so that an acquisition-function evaluation never waits for the host)
         else:

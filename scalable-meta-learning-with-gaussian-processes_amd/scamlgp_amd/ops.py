@@ -459,20 +459,25 @@ def weighted_prior_reduce(mu: Optional[torch.Tensor], cov: Optional[torch.Tensor
 
 
 def target_posterior(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Tensor, Xall: torch.Tensor, theta: torch.Tensor,
-                     train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False):
+                     train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False,
+                     factor: Optional[Dict[str, torch.Tensor]] = None):
     """Posterior mean / variance (original units) of the ScaML-GP target GP at the M query points behind the n training
     points in ``Xall`` (n + M, D), from the weighted source sums at the same points: cov_s (n, n + M), mean_s, var_s
     (n + M).  scaml_target_assemble_f64 -> scaml_potrf_batched_f64 (T = 1, jitter ladder) -> scaml_cho_solve_batched_f64
     -> scaml_target_finish_f64: four launches, no host synchronisation.  A factorisation that fails even with jitter shows as NaN
     in mu / var (the status stays on the device).  Returns (mu (M,), var (M,), info (1,), jitter (1,))."""
-    f = target_posterior_full(cov_s, mean_s, var_s, Xall, theta, train_targets, m_all, s_all, kind, observation_noise)
+    f = target_posterior_full(cov_s, mean_s, var_s, Xall, theta, train_targets, m_all, s_all, kind, observation_noise, factor)
     return f["mu"], f["var"], f["info"], f["jitter"]
 
 
 def target_posterior_full(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torch.Tensor, Xall: torch.Tensor, theta: torch.Tensor,
-                          train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False) -> Dict[str, torch.Tensor]:
-    """``target_posterior`` with its intermediates: dict(mu, var, info, jitter, alpha (n,) = Knn^-1 resid, Z (n, M) = Knn^-1 Knq) --
-    alpha and Z are what the input gradient of the posterior contracts against (``target_posterior_grad``)."""
+                          train_targets: torch.Tensor, m_all: float, s_all: float, kind: int, observation_noise: bool = False,
+                          factor: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """``target_posterior`` with its intermediates: dict(mu, var, info, jitter, alpha (n,) = Knn^-1 resid, Z (n, M) = Knn^-1 Knq,
+    factor) -- alpha and Z are what the input gradient of the posterior contracts against (``target_posterior_grad``).  ``factor``:
+    the ``factor`` entry of an earlier call with the SAME training block (cov_s[:, :n], mean_s[:n], theta, targets): the jittered
+    Cholesky of Knn is then reused instead of recomputed -- it does not depend on the query points (an acquisition optimisation
+    evaluates hundreds of query batches against one factor)."""
     n = int(train_targets.shape[0])
     W, D = Xall.shape
     M = W - n
@@ -493,7 +498,7 @@ def target_posterior_full(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torc
                                                 float(m_all), float(s_all), n, M, D, int(kind), _ptr(Knn), _ptr(resid), _ptr(Knq),
                                                 _ptr(mean_q), _ptr(var_q), _stream_handle())
         _lib.check_rc(rc, "scaml_target_assemble_f64")
-        f = potrf_batched(Knn, resid, want_linv=True)
+        f = factor if factor is not None else potrf_batched(Knn, resid, want_linv=True)
         mu, var = torch.empty((M,), **f64), torch.empty((M,), **f64)
         Z = None
         if M > 0:
@@ -502,7 +507,7 @@ def target_posterior_full(cov_s: torch.Tensor, mean_s: torch.Tensor, var_s: torc
                                                   float(theta[D + 1]) if observation_noise else 0.0, _ptr(f["info"]), n, M, _ptr(mu), _ptr(var),
                                                   _stream_handle())
             _lib.check_rc(rc, "scaml_target_finish_f64")
-    return dict(mu=mu, var=var, info=f["info"], jitter=f["jitter"], alpha=f["alpha"][0], Z=None if Z is None else Z[0])
+    return dict(mu=mu, var=var, info=f["info"], jitter=f["jitter"], alpha=f["alpha"][0], Z=None if Z is None else Z[0], factor=f)
 
 
 def source_posteriors_grad(Xq: torch.Tensor, Xa: Optional[torch.Tensor], X: torch.Tensor, theta: torch.Tensor, kind: int, Linv: torch.Tensor,
