@@ -499,7 +499,9 @@ class ScaMLGP:
         self.train_targets = ((self.train_Y - self.m_all) / self.s_all).squeeze(-1)
         # cached source posteriors at the target inputs, all tasks, no pruning (scamlgp/model.py:279-289)
         if self.n > 0:
-            p = self._stack.posterior(self.train_X, cov_first=self.n)
+            # (V of the training points: computed once here, reused by every later posterior / gradient call of this model)
+            va = self._train_VA() if (self.n <= 96 and self._stack.fit.get("Linv") is not None) else None
+            p = self._stack.posterior(self.train_X, cov_first=self.n, VA=va)
             # (sharded: every rank contributes its tasks' columns, one all-reduce each -- n <= ~80, tiny)
             self.source_means = sdist.gather_task_axis(p["mean"][self._idx].transpose(0, 1).contiguous(), self._shard)   # (n, T)
             self.source_covs = sdist.gather_task_axis(p["cov"][self._idx].permute(1, 2, 0).contiguous(), self._shard)    # (n, n, T)
