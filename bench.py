@@ -286,7 +286,9 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible "
                          "(SCAML_BENCH_REHEARSAL=1 rehearses the multi-rank control flow on one GPU; its numbers mean nothing)")
     device = torch.device("cuda", 0 if rehearsal else local_rank)
-    distributed = world > 1
+    # (SCAML_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank: the RCCL code path -- communicator set-up, the async
+    #  all-reduce, the barriers -- on a one-GPU box; the collective is then a copy, the number is the N = 1 number)
+    distributed = world > 1 or (os.environ.get("SCAML_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # one rank builds (a no-op when the parent launcher or an earlier run already did), the others wait
