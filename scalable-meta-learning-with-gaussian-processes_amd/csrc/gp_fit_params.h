@@ -68,4 +68,29 @@ struct BlockedFitParams {
   int round;
 };
 
+// Kernel-argument block of gp_fit_coop_kernel (csrc/gp_fit_coop.hip): the caller's arrays, then the workspace.
+struct CoopFitParams {
+  const double* X;          // (T, N, D)
+  const double* y;          // (T, N)
+  const double* theta;      // (T, D+2)
+  const int32_t* n_points;  // (T) or NULL
+  const double* jitter_in;  // (T) or NULL
+  double* L;                // (T, N, N)
+  double* alpha;            // (T, N)
+  double* quad;
+  double* logdet;
+  double* mll;
+  int32_t* info;
+  double* jitter_used;
+  double* Linv_diag;        // (T, N/16, 16, 16)
+  // workspace
+  unsigned* prog;           // (T, 32) per block column: attempt << 8 | block rows published   [zeroed before every launch]
+  unsigned* status;         // (T, 4) [0] attempts that failed, [1] attempt << 20 | failing pivot   [zeroed before every launch]
+  double* v;                // (T, N) L^-1 y
+  double* part;             // (T, 32, 2) per block column: sum v^2, sum 2 log diag
+  int T, N, D;
+  unsigned flags;
+  int parts;                // workgroups per task
+};
+
 }  // namespace scaml

@@ -60,6 +60,7 @@ struct Module {
   hipFunction_t tgt_fit = nullptr;
   hipFunction_t tgt_grad[2] = {nullptr, nullptr};
   hipFunction_t blk_round = nullptr, blk_finish = nullptr;
+  hipFunction_t coop[2] = {nullptr, nullptr};
   hipFunction_t blk_solve[2][2] = {}, blk_syrk[2] = {nullptr, nullptr};   // solve: [kind][D <= 8]
   hipFunction_t mllgrad_fused[4][2][2] = {};   // [size class NBT = 2, 4, 8, 16][kind][LDS-DMA staging]
   hipFunction_t mllgrad_split[2][2][2] = {};   // LDS-DMA staging, [N <= 128 | N <= 256 class][2 | 4 workgroups per task][kind]
@@ -135,6 +136,12 @@ struct Module {
     if ((e = hipModuleGetFunction(&tgt_finish, mod, "scaml_target_finish_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&tgt_fit, mod, "scaml_target_fit_kernel")) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)tgt_fit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    for (int kind = 0; kind < 2; ++kind) {
+      char name[128];
+      snprintf(name, sizeof(name), "_ZN5scaml18gp_fit_coop_kernelILi%dEEEvNS_13CoopFitParamsE", kind);
+      if ((e = hipModuleGetFunction(&coop[kind], mod, name)) != hipSuccess) return e;
+      if ((e = hipFuncSetAttribute((const void*)coop[kind], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    }
     if ((e = hipModuleGetFunction(&blk_round, mod, "scaml_blocked_round_kernel")) != hipSuccess) return e;
     if ((e = hipModuleGetFunction(&blk_finish, mod, "scaml_blocked_finish_kernel")) != hipSuccess) return e;
     for (int kind = 0; kind < 2; ++kind) {
@@ -296,6 +303,15 @@ BlockedLayout blocked_layout(int T, int N) {
 }
 }  // namespace
 
+// developer A/B switch: 0 by shape, 1 the 2 x 2 sequence of launches only, 2 the several-CUs-per-task kernel whenever it is launchable
+static int g_blocked_fit_path = getenv("SCAML_BLOCKED_FIT_PATH") ? atoi(getenv("SCAML_BLOCKED_FIT_PATH")) : 0;
+static int g_blocked_fit_last = 0;   // which one the last call took (1 / 2)
+int scaml_debug_blocked_fit_path(int mode) {
+  const int was = g_blocked_fit_path;
+  if (mode >= 0 && mode <= 2) g_blocked_fit_path = mode;
+  return mode == -1 ? g_blocked_fit_last : was;
+}
+
 long long scaml_gp_fit_blocked_workspace_bytes(int T, int N) {
   if (T < 0 || N <= 256 || N > 512) return 0;
   return (long long)blocked_layout(T, N).total;
@@ -319,6 +335,40 @@ int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* the
   hipError_t e = m.load();
   if (e != hipSuccess) { set_error("loading the gfx950 code object", e); return SCAML_E_LAUNCH; }
   char* ws = (char*)workspace;
+  {
+    // Several CUs per task (csrc/gp_fit_coop.hip) while the stack leaves CUs idle: P workgroups per task, ALL resident at once
+    // (one per CU: the dynamic LDS request is kept above half a CU's), so the launch is only taken when T P <= #CUs.
+    if (m.num_cus == 0) {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.num_cus = cus;
+      if (m.num_cus <= 0) m.num_cus = 256;
+    }
+    const int nbc = (N + 31) / 32;
+    int parts = m.num_cus / T;
+    parts = parts > 8 ? 8 : parts;
+    parts = parts > nbc ? nbc : parts;
+    const size_t lds_coop = (size_t)(64 + 16 + 32 + 32 + 16 + 8 + 5 * 32 * 33 + (size_t)N * (D | 1)) * sizeof(double);
+    const size_t flag_bytes = (((size_t)T * 36 * 4) + 15) & ~(size_t)15;
+    const size_t need = flag_bytes + (size_t)T * N * 8 + (size_t)T * 64 * 8;
+    const bool take = g_blocked_fit_path == 2 ? parts >= 1 : (g_blocked_fit_path == 0 && parts >= 2);
+    if (take && D <= 16 && lds_coop <= 160 * 1024 && need <= (size_t)workspace_bytes) {
+      hipStream_t st = (hipStream_t)stream;
+      if ((e = hipMemsetAsync(ws, 0, flag_bytes, st)) != hipSuccess) { set_error("hipMemsetAsync(coop flags)", e); return SCAML_E_LAUNCH; }
+      scaml::CoopFitParams c{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag,
+                             (unsigned*)ws, (unsigned*)ws + (size_t)T * 32, (double*)(ws + flag_bytes), (double*)(ws + flag_bytes) + (size_t)T * N,
+                             T, N, D, flags, parts};
+      size_t csize = sizeof(c);
+      void* cconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &c, HIP_LAUNCH_PARAM_BUFFER_SIZE, &csize, HIP_LAUNCH_PARAM_END};
+      const size_t lds_req = lds_coop > 82 * 1024 ? lds_coop : 82 * 1024;
+      const int t8 = (T + 7) / 8 * 8;
+      if ((e = hipModuleLaunchKernel(m.coop[kind], (unsigned)(t8 * parts), 1, 1, 512, 1, 1, (unsigned)lds_req, st, nullptr, cconfig)) != hipSuccess) {
+        set_error("hipModuleLaunchKernel(gp_fit_coop)", e); return SCAML_E_LAUNCH;
+      }
+      g_blocked_fit_last = 2;
+      return SCAML_OK;
+    }
+    g_blocked_fit_last = 1;
+  }
   const int N1 = 256, N2 = N - N1, NBT = N / 16;
   scaml::BlockedFitParams p{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag,
                             (double*)(ws + lay.S), (double*)(ws + lay.Vimg), (double*)(ws + lay.r2), (double*)(ws + lay.q12), (double*)(ws + lay.jit_cur),

@@ -137,6 +137,8 @@ def _load() -> ctypes.CDLL:
                                          + [ctypes.c_longlong, c_void_p])
     lib.scaml_debug_target_fit_path.restype = c_int
     lib.scaml_debug_target_fit_path.argtypes = [c_int]
+    lib.scaml_debug_blocked_fit_path.restype = c_int
+    lib.scaml_debug_blocked_fit_path.argtypes = [c_int]
     lib.scaml_debug_force_two_launch_grad.restype = c_int
     lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib
