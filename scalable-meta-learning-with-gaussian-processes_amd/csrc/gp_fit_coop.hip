@@ -46,10 +46,17 @@ constexpr unsigned CF_DEAD = 255u;      // failure count that stops every attemp
 #else
 #define CF_STAMP(k) do { } while (0)
 #endif
+#define CF_FSTAMP(k) do { const int j = part + 30 * P; CF_STAMP(k); } while (0)   // (slot 30: inside the finish)
 
 __device__ __forceinline__ void cf_settle(d4_t& v) { asm volatile("s_nop 15\n\ts_nop 2" : "+v"(v)); }   // gfx950: last MFMA result pair not interlocked
 // workgroup barrier for LDS traffic only: __syncthreads() also waits for every global load in flight (its fences), which undoes a prefetch
 __device__ __forceinline__ void cf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// payload store: write-through (sc1) in general; a plain store where every workgroup of the task sits on the same XCD (`near`): the line
+// then stays in that XCD's L2, which is where the consumers' sc1 loads look it up (an sc1 store drops it: every consumer read goes to memory)
+__device__ __forceinline__ void cf_store(double* ptr, double v, bool near) {
+  if (near) *ptr = v;
+  else __hip_atomic_store(ptr, v, CF_RLX_AGENT);
+}
 __device__ __forceinline__ void cf_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // 1 / sqrt(d) for ANY positive finite double, without a branch (rsqrt_pos's slow path is one: with it in the middle of the pivot sweep
@@ -238,7 +245,47 @@ __device__ __forceinline__ d4_t cf_accumulate(d4_t acc, __amdgpu_buffer_rsrc_t r
     b1 = cf_load2<SAME>(rsA, rs, baseA, baseB, c + 4, c_hi);
     if (c + 2 < c_hi) acc = cf_mma2(b2, acc);
   }
+  // (settled here, not at the use: the registers of one slot's tile are reused for the next slot's, and a VALU write into the last
+  //  result pair 17 wait states behind the MFMA is as unprotected as a read -- found by the build's hazard audit)
+  cf_settle(acc);
   return acc;
+}
+
+// The forward substitution's products (L_j,0:j v for the 32 rows of block row j) in ONE pipeline: the finished part of v as a one-row A tile
+// (its descriptor ends after that row: the other 15 rows load as zeros), the two 16-row tiles of the block row as B.
+struct CfOpsV {
+  cf_u4 v0, v1, p0, p1, q0, q1;
+};
+__device__ __forceinline__ CfOpsV cf_loadv(__amdgpu_buffer_rsrc_t rsV, __amdgpu_buffer_rsrc_t rs, unsigned baseV, unsigned baseB, unsigned rowskip, int s, int s_hi) {
+  const unsigned off = s < s_hi ? 128u * (unsigned)s : 0xC0000000u;
+  CfOpsV o;
+  o.v0 = __builtin_amdgcn_raw_buffer_load_b128(rsV, baseV + off, 0, 16);
+  o.v1 = __builtin_amdgcn_raw_buffer_load_b128(rsV, baseV + off + 16, 0, 16);
+  o.p0 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + off, 0, 16);
+  o.p1 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + off + 16, 0, 16);
+  o.q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + rowskip + off, 0, 16);
+  o.q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + rowskip + off + 16, 0, 16);
+  return o;
+}
+__device__ __forceinline__ void cf_mmav(const CfOpsV& o, d4_t& r0, d4_t& r1) {
+  r0 = cf_mma(CfOps{o.v0, o.v1, o.p0, o.p1}, r0);
+  r1 = cf_mma(CfOps{o.v0, o.v1, o.q0, o.q1}, r1);
+}
+__device__ __forceinline__ void cf_accumulate_v(d4_t& r0, d4_t& r1, __amdgpu_buffer_rsrc_t rsV, __amdgpu_buffer_rsrc_t rs, int N, int rowB, int c_lo, int c_hi, int lc,
+                                                int lq) {
+  const unsigned baseV = (unsigned)(((size_t)lc * N + 4 * lq) * 8), baseB = (unsigned)(((size_t)(rowB + lc) * N + 4 * lq) * 8), rowskip = (unsigned)(16 * N * 8);
+  const int s_hi = 2 * c_hi;
+  CfOpsV b0 = cf_loadv(rsV, rs, baseV, baseB, rowskip, 2 * c_lo, s_hi), b1 = cf_loadv(rsV, rs, baseV, baseB, rowskip, 2 * c_lo + 1, s_hi), b2;
+  for (int s = 2 * c_lo; s < s_hi; s += 3) {
+    b2 = cf_loadv(rsV, rs, baseV, baseB, rowskip, s + 2, s_hi);
+    cf_mmav(b0, r0, r1);
+    b0 = cf_loadv(rsV, rs, baseV, baseB, rowskip, s + 3, s_hi);
+    if (s + 1 < s_hi) cf_mmav(b1, r0, r1);
+    b1 = cf_loadv(rsV, rs, baseV, baseB, rowskip, s + 4, s_hi);
+    if (s + 2 < s_hi) cf_mmav(b2, r0, r1);
+  }
+  cf_settle(r0);
+  cf_settle(r1);
 }
 
 template <int KIND>
@@ -260,9 +307,9 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
   double* tv = invl + 16;                // [32] right-hand side of the column's forward substitution
   double* rvs = tv + 32;                 // [32] L_j,0:j v
   double* red = rvs + 32;                // [16]
-  int* ctrl = (int*)(red + 16);          // [0] abandon the attempt, [1] failing pivot (local)
-  double* Cb = red + 16 + 8;             // [3][32][CF_BP] the chunk's blocks before the multiplication by L_jj^-T
-  double* Dg = Cb + 3 * CF_BS;           // L_jj
+  int* ctrl = (int*)(red + 16);          // [0] abandon the attempt, [1] failing pivot (local), [2] all parts of the task on one XCD
+  double* Cb = red + 16 + 8;             // [4][32][CF_BP] the chunk's blocks before the multiplication by L_jj^-T
+  double* Dg = Cb + 4 * CF_BS;           // L_jj
   double* Wb = Dg + CF_BS;               // L_jj^-1
   double* Xs = Wb + CF_BS;               // [N][DP] x / lengthscale
 
@@ -272,7 +319,6 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
   double* Lg = p.L + (size_t)task * N * N;
   double* Wg = p.Linv_diag + (size_t)task * (N / 16) * 256;
   double* vg = p.v + (size_t)task * N;
-  double* pg = p.part + (size_t)task * 64;
   unsigned* prog = p.prog + (size_t)task * 32;
   unsigned* status = p.status + (size_t)task * 4;
   const double os = th[D], noise = th[D + 1];
@@ -288,6 +334,29 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
     Xs[r * DP + d] = r < n ? Xg[e] * invl[d] : 0.0;
   }
   __syncthreads();
+
+  // XCD census: do all P workgroups of this task share an XCD (and with it an L2)?  The host's block map puts them on one (blockIdx & 7
+  // is the same), but placement is the dispatcher's business: every part publishes the XCC id it actually runs on, and only if all P agree
+  // are payload stores plain.  Results do not depend on the answer, only the speed of the hand-offs does.
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID, bits [3:0]
+    __hip_atomic_store(p.xcc + (size_t)task * 8 + part, xcc + 1u, CF_RLX_AGENT);
+  }
+  if (wave == 0) {
+    bool same = false;
+    for (int spins = 0; spins < CF_SPIN_LIMIT; ++spins) {
+      const unsigned mine = __hip_atomic_load(p.xcc + (size_t)task * 8 + part, CF_RLX_AGENT);
+      const unsigned other = lane < P ? __hip_atomic_load(p.xcc + (size_t)task * 8 + lane, CF_RLX_AGENT) : mine;
+      if (__ballot(other == 0u || mine == 0u) == 0ull) {
+        same = __ballot(other != mine) == 0ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) ctrl[2] = (same && !(p.flags & 0x80000000u)) ? 1 : 0;
+  }
+  __syncthreads();
+  const bool near = ctrl[2] != 0;
 
   // descriptors of the two handed-off arrays this workgroup loads from (wave-uniform by construction)
   // (rows >= n are an identity block that is never written -- include/scaml_gp.h --: the descriptor ends at row n, loads past it return 0)
@@ -334,11 +403,11 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       bool on;
     };
     d4_t rv1 = {0.0, 0.0, 0.0, 0.0};   // second accumulator of the mode-2 slot (rows 16 .. 31 of L_j,0:j v)
-    auto advance = [&](int j, Slot& s0, Slot& s1, Slot& s2, int target) {
-      // until slot `target` (0, 1 or 2) has all j columns; the slots behind it take what is ready, two columns at a time
+    auto advance = [&](int j, Slot& s0, Slot& s1, Slot& s2, Slot& s3, int target) {
+      // until slot `target` (0 .. 3) has all j columns; the slots behind it take what is ready, two columns at a time
       int spins = 0;
       for (;;) {
-        Slot& st_ = target == 0 ? s0 : (target == 1 ? s1 : s2);
+        Slot& st_ = target == 0 ? s0 : (target == 1 ? s1 : (target == 2 ? s2 : s3));
         if (!st_.on || st_.done >= j) return;
         unsigned pv = 0xffffffffu;
         if (lane < j) pv = __hip_atomic_load(prog + lane, CF_RLX_AGENT);
@@ -349,8 +418,8 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
         asm volatile("" ::: "memory");   // (the payload loads below stay below the poll)
         bool moved = false;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          Slot& sl = k == 0 ? s0 : (k == 1 ? s1 : s2);
+        for (int k = 0; k < 4; ++k) {
+          Slot& sl = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
           if (k < target || !sl.on || sl.done >= j || moved) continue;
           const unsigned long long m = __ballot(lane >= j || (tag_ok && cnt >= sl.row - lane + 1));
           int ready = m == ~0ull ? j : __builtin_ctzll(~m);
@@ -358,8 +427,7 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
           if (ready > sl.done) {
             if (k != target && ready > sl.done + 2) ready = sl.done + 2;
             if (sl.mode == 2) {
-              sl.acc = cf_accumulate<false>(sl.acc, rsV, rsL, N, 0, 32 * j, sl.done, ready, lc, lq);
-              rv1 = cf_accumulate<false>(rv1, rsV, rsL, N, 0, 32 * j + 16, sl.done, ready, lc, lq);
+              cf_accumulate_v(sl.acc, rv1, rsV, rsL, N, 32 * j, sl.done, ready, lc, lq);
             } else if (sl.mode == 1) {
               sl.acc = cf_accumulate<true>(sl.acc, rsL, rsL, N, 32 * sl.row + 16 * ti, 32 * j + 16 * tj, sl.done, ready, lc, lq);
             } else {
@@ -400,7 +468,7 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
     auto sum_tile = [&](int j, int i, double* Cdst) {
       const d4_t kt = kvals(j, i);
       Slot s{{0.0, 0.0, 0.0, 0.0}, i, 0, 0, true}, off{{0.0, 0.0, 0.0, 0.0}, 0, 0, 0, false};
-      advance(j, s, off, off, 0);
+      advance(j, s, off, off, off, 0);
       if (!gone) put(s, kt, Cdst);
     };
     // tile (ti, tj) of L_ij = C_ij L_jj^-T on the matrix cores, written through (sc1): rows / columns past n are never written
@@ -417,7 +485,7 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = 32 * i + 16 * ti + lq + 4 * g;
-          if (row < n) __hip_atomic_store(Lg + (size_t)row * N + col, out[g], CF_RLX_AGENT);
+          if (row < n) cf_store(Lg + (size_t)row * N + col, out[g], near);
         }
       }
     };
@@ -432,16 +500,27 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       }
       CF_STAMP(0);
       // ---- first chunk: the diagonal block and the TWO block rows below it (what the next column's first chunk starts from) ----
-      const int nb0 = NB - j < 3 ? NB - j : 3;
+      // Block rows of the first chunk: the diagonal block and the two below it -- three in an odd column, FOUR in an even one, so that the
+      // chunks behind start at an even block row in EVERY column: a chunk {2 m, 2 m + 1} then needs the same chunk of the column before
+      // it and nothing else (with cuts relative to j it needs two consecutive chunks of that column, two chunk times per column, and
+      // trails the diagonal chain by more with every column).
+      const int want0 = (j & 1) ? 3 : 4;
+      const int nb0 = NB - j < want0 ? NB - j : want0;
       const d4_t z4 = {0.0, 0.0, 0.0, 0.0};
       // slot 0: diagonal block (tiles (0,0), (1,0), (1,1); the fourth wave: L_j,0:j v) / block row j + 1; slot 1: block row j + 2 (summed
-      // by waves 4-7 while wave 0 factors the diagonal block); slot 2: this wave's tile of the chunk behind (block rows j + 3, j + 4)
+      // by waves 4-7 while wave 0 factors the diagonal block); slot 2: in an even column block row j + 3 (the same waves, right behind),
+      // in an odd one this wave's tile of the first chunk behind (block rows j + 3, j + 4)
+      const bool four = nb0 > 3;
       Slot s0{z4, j + wb, wb == 0 ? (wq == 1 ? 2 : (wq == 2 ? 0 : 1)) : 0, 0, wb == 0 || nb0 > 1};
       Slot s1{z4, j + 2, 0, 0, wb == 1 && nb0 > 2};
-      Slot s2{z4, j + 3 + wb, 0, 0, j + 3 + wb < NB};
+      Slot s2{z4, (j & 1) ? j + 3 + wb : j + 3, 0, 0, (j & 1) ? (j + 3 + wb < NB) : (wb == 1 && four)};
+      // slot 3: this wave's tile of the next chunk behind those (block rows j + 5, j + 6 in an odd column, j + 4, j + 5 in an even one)
+      const int row3 = ((j & 1) ? j + 5 : j + 4) + wb;
+      Slot s3{z4, row3, 0, 0, row3 < NB};
       rv1 = z4;
       const d4_t kt0 = (s0.on && s0.mode != 2) ? kvals(j, s0.row) : z4;
-      advance(j, s0, s1, s2, 0);
+      const d4_t kt2 = s2.on ? kvals(j, s2.row) : z4;
+      advance(j, s0, s1, s2, s3, 0);
       if (!gone && s0.on) put(s0, kt0, Cb + wb * CF_BS);
       CF_STAMP(2);
       __syncthreads();
@@ -472,8 +551,12 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       } else if (wb == 1) {
         if (s1.on) {                             // (block row j + 2, during the factorisation of the diagonal block)
           const d4_t kt1 = kvals(j, s1.row);
-          advance(j, s0, s1, s2, 1);
+          advance(j, s0, s1, s2, s3, 1);
           if (!gone) put(s1, kt1, Cb + 2 * CF_BS);
+          if (!gone && four) {
+            advance(j, s0, s1, s2, s3, 2);
+            if (!gone) put(s2, kt2, Cb + 3 * CF_BS);
+          }
         }
       }
       __syncthreads();
@@ -481,27 +564,17 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       if (gone) break;
       CF_STAMP(5);
       if (wave == 1) {
-        // v_j = L_jj^-1 (y_j - L_j,0:j v), the column's share of quad and logdet
-        double vj = 0.0, q = 0.0, ld = 0.0;
-        if (lane < 32) {
-          for (int k = 0; k <= lane; ++k) vj = __builtin_fma(Wb[lane * CF_BP + k], tv[k], vj);
-          q = vj * vj;
-          ld = 2.0 * log(Dg[lane * CF_BP + lane]);
-          if (32 * j + lane < N) __hip_atomic_store(vg + 32 * j + lane, vj, CF_RLX_AGENT);
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-          q += __shfl_xor(q, o);
-          ld += __shfl_xor(ld, o);
-        }
-        if (lane == 0) {
-          __hip_atomic_store(pg + 2 * j, q, CF_RLX_AGENT);
-          __hip_atomic_store(pg + 2 * j + 1, ld, CF_RLX_AGENT);
-        }
+        // v_j = L_jj^-1 (y_j - L_j,0:j v): row r = lane & 31, the two half-waves take the columns k < 16 / k >= 16
+        const int r = lane & 31, h = lane >> 5;
+        double vj = 0.0;
+        for (int k = 16 * h; k < 16 * h + 16; ++k) vj = __builtin_fma(k <= r ? Wb[r * CF_BP + k] : 0.0, tv[k], vj);
+        vj += __shfl_xor(vj, 32);
+        if (lane < 32 && 32 * j + lane < N) cf_store(vg + 32 * j + lane, vj, near);
       } else if (wave >= 2 && wave < 4) {
         // the inverses of the two 16 x 16 diagonal blocks (what the posterior kernels take)
         const int h = wave - 2, blk = 2 * j + h;
         if (16 * blk < N)
-          for (int e = lane; e < 256; e += 64) __hip_atomic_store(Wg + (size_t)blk * 256 + e, Wb[(16 * h + (e >> 4)) * CF_BP + 16 * h + (e & 15)], CF_RLX_AGENT);
+          for (int e = lane; e < 256; e += 64) cf_store(Wg + (size_t)blk * 256 + e, Wb[(16 * h + (e >> 4)) * CF_BP + 16 * h + (e & 15)], near);
       }
       if (wb == 0) {
         // the diagonal block's tiles go out as they are (the upper tile only on request) ...
@@ -511,12 +584,13 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int row = 32 * j + 16 * ti + lq + 4 * g;
-            if (row < n) __hip_atomic_store(Lg + (size_t)row * N + col, Dg[(16 * ti + lq + 4 * g) * CF_BP + 16 * tj + lc], CF_RLX_AGENT);
+            if (row < n) cf_store(Lg + (size_t)row * N + col, Dg[(16 * ti + lq + 4 * g) * CF_BP + 16 * tj + lc], near);
           }
         }
         if (nb0 > 1) trsm_store(j, j + 1, Cb + CF_BS);   // ... and the first block row below
       } else if (nb0 > 2) {
         trsm_store(j, j + 2, Cb + 2 * CF_BS);
+        if (four) trsm_store(j, j + 3, Cb + 3 * CF_BS);
       }
       CF_STAMP(6);
       cf_drain();
@@ -524,13 +598,18 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       CF_STAMP(7);
       if (tid == 0) __hip_atomic_store(prog + j, ((unsigned)attempt << 8) | (unsigned)nb0, CF_RLX_AGENT);
       // ---- the rest of the column, two block rows at a time ----
-      for (int i0 = j + 3; i0 < NB; i0 += 2) {
+      for (int i0 = j + nb0; i0 < NB;) {
         const int nblk = NB - i0 < 2 ? NB - i0 : 2;
-        if (i0 == j + 3) {
+        if (i0 == j + 3) {   // (odd column: the chunk whose sums were started in the waiting time)
           if (s2.on) {
-            const d4_t kt2 = kvals(j, s2.row);
-            advance(j, s0, s1, s2, 2);
+            advance(j, s0, s1, s2, s3, 2);
             if (!gone) put(s2, kt2, Cb + wb * CF_BS);
+          }
+        } else if (i0 + wb == row3) {
+          if (s3.on) {
+            const d4_t kt3 = kvals(j, row3);
+            advance(j, s0, s1, s2, s3, 3);
+            if (!gone) put(s3, kt3, Cb + wb * CF_BS);
           }
         } else if (wb < nblk) {
           sum_tile(j, i0 + wb, Cb + wb * CF_BS);
@@ -542,6 +621,7 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
         cf_drain();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(prog + j, ((unsigned)attempt << 8) | (unsigned)(i0 - j + nblk), CF_RLX_AGENT);
+        i0 += nblk;
       }
     }
     { const int j = part + 31 * P; CF_STAMP(0); }   // (slot 31: all columns of this part done)
@@ -590,48 +670,73 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
     {
       double* vs = Cb;   // [N] (N <= 2 * CF_BS)
       for (int r = tid; r < N; r += blockDim.x) vs[r] = __hip_atomic_load(vg + r, CF_RLX_AGENT);
-      if (tid < 2 * NB) rvs[tid] = __hip_atomic_load(pg + tid, CF_RLX_AGENT);   // (all at once: a serial loop of sc1 loads is a chain of round trips)
-      __syncthreads();
-      if (tid == 0) {
+      {
+        // quad = v . v, logdet = 2 sum log L_rr: one element per thread, summed in a fixed order (waves, then lanes)
         double q = 0.0, ld = 0.0;
-        for (int c = 0; c < NB; ++c) {   // fixed order
-          q += rvs[2 * c];
-          ld += rvs[2 * c + 1];
+        for (int r = tid; r < N; r += blockDim.x) {
+          const double vr = __hip_atomic_load(vg + r, CF_RLX_AGENT);
+          q += vr * vr;
+          if (r < n) ld += 2.0 * log(__hip_atomic_load(Lg + (size_t)r * N + r, CF_RLX_AGENT));
         }
-        p.info[task] = 0;
-        if (p.jitter_used) p.jitter_used[task] = ladder;
-        if (p.quad) p.quad[task] = q;
-        if (p.logdet) p.logdet[task] = ld;
-        if (p.mll) p.mll[task] = n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0;
+        for (int o = 32; o > 0; o >>= 1) {
+          q += __shfl_xor(q, o);
+          ld += __shfl_xor(ld, o);
+        }
+        if (lane == 0) {
+          rvs[wave] = q;
+          rvs[8 + wave] = ld;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          q = 0.0;
+          ld = 0.0;
+          for (int w = 0; w < 8; ++w) {
+            q += rvs[w];
+            ld += rvs[8 + w];
+          }
+          p.info[task] = 0;
+          if (p.jitter_used) p.jitter_used[task] = ladder;
+          if (p.quad) p.quad[task] = q;
+          if (p.logdet) p.logdet[task] = ld;
+          if (p.mll) p.mll[task] = n > 0 ? -0.5 * (q + ld + n * 1.8378770664093454836) / n : 0.0;
+        }
+        __syncthreads();
       }
-      __syncthreads();
       // row-push form by 16-row blocks, last to first: alpha_b = W_b^T v_b, then v_k -= sum_r L[16 b + r][k] alpha_b[r] for k < 16 b
       // (the rows of L are contiguous: thread k reads column k of the block row, coalesced; the next block row is fetched while this
       //  one is used)
+      CF_FSTAMP(0);
       const int nb16 = N / 16;
       double* ab = tv;      // [16]
       double* Wl = Dg;      // [256] W_b of the current step (row-major)
-      // (blockDim.x = 512 >= N - 16: every thread owns one column of the pushes.  The rows of L and W_b of a step depend on nothing
-      //  computed here: they are fetched FOUR steps ahead -- a step is ~150 ns of arithmetic, a load ~1.2 us away; W_b travels as one
-      //  element per thread and is put into LDS a step ahead of its use)
-      double lr[4][16], wq4[4];
-      // (unconditional buffer loads, sc1: what a thread does not need gets an offset beyond the descriptor's end and loads as zero --
-      //  a conditional load is a branch, and the compiler waits for every load in flight at its join)
-      typedef unsigned cf_u2 __attribute__((ext_vector_type(2)));
+      // Thread t < 256 owns the columns 2 t, 2 t + 1 of the pushes (N <= 512); the 16 rows of L of a step come as 16-byte sc1 buffer
+      // loads, CF_FD steps ahead (they depend on nothing computed here; a step is ~150 ns of arithmetic, a load ~1 us away), W_b as one
+      // element per thread, put into LDS a step ahead of its use.  No load is conditional (a conditional load is a branch, and the
+      // compiler waits for every load in flight at its join): what a thread does not need gets an offset beyond the descriptor's end
+      // and loads as zero.  The upper four waves only take part in the barriers.
+      constexpr int CF_FD = 3;
+      cf_d2 lr[CF_FD][16];
+      double wq4[CF_FD];
       const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(Wg, 0, nb16 * 256 * 8, 0x00020000);
-      auto fetch = [&](int b, double* l, double& w) {
-        const unsigned base = (b >= 0 && tid < 16 * b) ? (unsigned)(((size_t)(16 * b) * N + tid) * 8) : 0xC0000000u;
+      const bool loader = tid < 256;
+      auto fetch = [&](int b, cf_d2* l, double& w) {
+        const unsigned base = (b >= 0 && 2 * tid < 16 * b) ? (unsigned)(((size_t)(16 * b) * N + 2 * tid) * 8) : 0xC0000000u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) l[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsL, base + (unsigned)(r * N * 8), 0, 16));
-        w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsW, (b >= 0 && tid < 256) ? (unsigned)((b * 256 + tid) * 8) : 0xC0000000u, 0, 16));
+        for (int r = 0; r < 16; ++r) l[r] = __builtin_bit_cast(cf_d2, __builtin_amdgcn_raw_buffer_load_b128(rsL, base + (unsigned)(r * N * 8), 0, 16));
+        typedef unsigned cf_u2 __attribute__((ext_vector_type(2)));
+        w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsW, b >= 0 ? (unsigned)((b * 256 + tid) * 8) : 0xC0000000u, 0, 16));
       };
+      if (loader) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) fetch(nb16 - 1 - u, lr[u], wq4[u]);
-      if (tid < 256) Wl[tid] = wq4[0];
+        for (int u = 0; u < CF_FD; ++u) fetch(nb16 - 1 - u, lr[u], wq4[u]);
+        Wl[tid] = wq4[0];
+      }
       cf_lds_barrier();
-      for (int b0 = nb16 - 1; b0 >= 0; b0 -= 4) {
+      CF_FSTAMP(1);
+      for (int b0 = nb16 - 1; b0 >= 0; b0 -= CF_FD) {
+        if (((nb16 - 1 - b0) / CF_FD) < 8) CF_FSTAMP(2 + ((nb16 - 1 - b0) / CF_FD));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CF_FD; ++u) {
           const int b = b0 - u;
           if (b >= 0) {
             if (tid < 16) {
@@ -642,14 +747,21 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
               if (16 * b + tid < n) p.alpha[(size_t)task * N + 16 * b + tid] = a;
             }
             cf_lds_barrier();
-            if (tid < 16 * b) {
-              double sacc = vs[tid];
+            if (loader) {
+              if (2 * tid < 16 * b) {
+                double sa = vs[2 * tid], sb = vs[2 * tid + 1];
 #pragma unroll
-              for (int r = 0; r < 16; ++r) sacc = __builtin_fma(-lr[u][r], ab[r], sacc);
-              vs[tid] = sacc;
+                for (int r = 0; r < 16; ++r) {
+                  const double ar = ab[r];
+                  sa = __builtin_fma(-lr[u][r][0], ar, sa);
+                  sb = __builtin_fma(-lr[u][r][1], ar, sb);
+                }
+                vs[2 * tid] = sa;
+                vs[2 * tid + 1] = sb;
+              }
+              Wl[tid] = wq4[(u + 1) % CF_FD];   // W of the next step
+              fetch(b - CF_FD, lr[u], wq4[u]);
             }
-            if (tid < 256) Wl[tid] = wq4[(u + 1) & 3];   // W of the next step
-            fetch(b - 4, lr[u], wq4[u]);
             cf_lds_barrier();
           }
         }

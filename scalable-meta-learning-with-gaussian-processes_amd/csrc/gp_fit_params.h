@@ -86,6 +86,7 @@ struct CoopFitParams {
   // workspace
   unsigned* prog;           // (T, 32) per block column: attempt << 8 | block rows published   [zeroed before every launch]
   unsigned* status;         // (T, 4) [0] attempts that failed, [1] attempt << 20 | failing pivot   [zeroed before every launch]
+  unsigned* xcc;            // (T, 8) 1 + the XCC id every part runs on   [zeroed before every launch]
   double* v;                // (T, N) L^-1 y
   double* part;             // (T, 32, 2) per block column: sum v^2, sum 2 log diag
   int T, N, D;

@@ -306,6 +306,7 @@ BlockedLayout blocked_layout(int T, int N) {
 // developer A/B switch: 0 by shape, 1 the 2 x 2 sequence of launches only, 2 the several-CUs-per-task kernel whenever it is launchable
 static int g_blocked_fit_path = getenv("SCAML_BLOCKED_FIT_PATH") ? atoi(getenv("SCAML_BLOCKED_FIT_PATH")) : 0;
 static int g_blocked_fit_last = 0;   // which one the last call took (1 / 2)
+static const bool g_coop_far = getenv("SCAML_COOP_FAR") != nullptr;   // developer A/B: write-through payload stores even when a task's workgroups share an XCD
 int scaml_debug_blocked_fit_path(int mode) {
   const int was = g_blocked_fit_path;
   if (mode >= 0 && mode <= 2) g_blocked_fit_path = mode;
@@ -347,16 +348,16 @@ int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* the
     int parts = m.num_cus / T;
     parts = parts > 8 ? 8 : parts;
     parts = parts > nbc ? nbc : parts;
-    const size_t lds_coop = (size_t)(64 + 16 + 32 + 32 + 16 + 8 + 5 * 32 * 33 + (size_t)N * (D | 1)) * sizeof(double);
-    const size_t flag_bytes = (((size_t)T * 36 * 4) + 15) & ~(size_t)15;
+    const size_t lds_coop = (size_t)(64 + 16 + 32 + 32 + 16 + 8 + 6 * 32 * 33 + (size_t)N * (D | 1)) * sizeof(double);
+    const size_t flag_bytes = (((size_t)T * 44 * 4) + 15) & ~(size_t)15;
     const size_t need = flag_bytes + (size_t)T * N * 8 + (size_t)T * 64 * 8;
     const bool take = g_blocked_fit_path == 2 ? parts >= 1 : (g_blocked_fit_path == 0 && parts >= 2);
     if (take && D <= 16 && lds_coop <= 160 * 1024 && need <= (size_t)workspace_bytes) {
       hipStream_t st = (hipStream_t)stream;
       if ((e = hipMemsetAsync(ws, 0, flag_bytes, st)) != hipSuccess) { set_error("hipMemsetAsync(coop flags)", e); return SCAML_E_LAUNCH; }
       scaml::CoopFitParams c{X, y, theta, n_points, jitter_in, L, alpha, quad, logdet, mll, info, jitter_used, Linv_diag,
-                             (unsigned*)ws, (unsigned*)ws + (size_t)T * 32, (double*)(ws + flag_bytes), (double*)(ws + flag_bytes) + (size_t)T * N,
-                             T, N, D, flags, parts};
+                             (unsigned*)ws, (unsigned*)ws + (size_t)T * 32, (unsigned*)ws + (size_t)T * 36, (double*)(ws + flag_bytes), (double*)(ws + flag_bytes) + (size_t)T * N,
+                             T, N, D, flags | (g_coop_far ? 0x80000000u : 0u), parts};
       size_t csize = sizeof(c);
       void* cconfig[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &c, HIP_LAUNCH_PARAM_BUFFER_SIZE, &csize, HIP_LAUNCH_PARAM_END};
       const size_t lds_req = lds_coop > 82 * 1024 ? lds_coop : 82 * 1024;

@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 assert int(info.abs().max()) == 0
 P = min(8, (N + 31) // 32, 256 // T)
 NB = (N + 31) // 32
-flag_bytes = (T * 36 * 4 + 15) // 16 * 16
+flag_bytes = (T * 44 * 4 + 15) // 16 * 16
 off = flag_bytes + (T * N + T * 64) * 8
 st = ws[off:off + 8 * 32 * 16 * 8].view(torch.float64).view(8, 32, 16).cpu().numpy() * 0.01   # -> us
 t0 = min(st[p, 0, 0] for p in range(P))
@@ -41,4 +41,4 @@ for j in range(NB):
     nxt = (st[p, k + 1, 0] if (j + P < NB) else st[p, 31, 0]) - t0
     print(f" {j:3d} {p:4d} | {s[0]:6.1f} {s[2]:7.1f} {s[3]-s[2]:7.1f} {s[4]-s[3]:7.1f} ({s[8]-s[3]:4.1f} {s[9]-s[8]:4.1f} {s[10]-s[9]:4.1f} {s[4]-s[10]:4.1f}) {s[5]-s[4]:7.1f} {s[6]-s[5]:7.1f} {s[7]-s[6]:7.1f}  {s[7]:7.1f} | {nxt:7.1f}")
 lp = (NB - 1) % P
-print(f"finish (part {lp}): {st[lp, 31, 0] - t0:.1f} -> {st[lp, 31, 1] - t0:.1f} us")
+print(f"finish (part {lp}): {st[lp, 31, 0] - t0:.1f} -> {st[lp, 31, 1] - t0:.1f} us; inside: scalars done {st[lp, 30, 0] - t0:.1f}, first rows in {st[lp, 30, 1] - t0:.1f}, every 4 steps: " + " ".join(f"{st[lp, 30, 2 + k] - t0:.1f}" for k in range(8)))
