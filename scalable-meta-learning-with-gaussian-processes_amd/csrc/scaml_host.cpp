@@ -306,7 +306,12 @@ BlockedLayout blocked_layout(int T, int N) {
 // developer A/B switch: 0 by shape, 1 the 2 x 2 sequence of launches only, 2 the several-CUs-per-task kernel whenever it is launchable
 static int g_blocked_fit_path = getenv("SCAML_BLOCKED_FIT_PATH") ? atoi(getenv("SCAML_BLOCKED_FIT_PATH")) : 0;
 static int g_blocked_fit_last = 0;   // which one the last call took (1 / 2)
-static const bool g_coop_far = getenv("SCAML_COOP_FAR") != nullptr;   // developer A/B: write-through payload stores even when a task's workgroups share an XCD
+static bool g_coop_far = getenv("SCAML_COOP_FAR") != nullptr;   // developer A/B / tests: write-through payload stores even when a task's workgroups share an XCD
+int scaml_debug_coop_far(int on) {
+  const int was = g_coop_far ? 1 : 0;
+  if (on == 0 || on == 1) g_coop_far = on == 1;
+  return was;
+}
 int scaml_debug_blocked_fit_path(int mode) {
   const int was = g_blocked_fit_path;
   if (mode >= 0 && mode <= 2) g_blocked_fit_path = mode;
@@ -351,7 +356,9 @@ int scaml_gp_fit_blocked_f64(const double* X, const double* y, const double* the
     const size_t lds_coop = (size_t)(64 + 16 + 32 + 32 + 16 + 8 + 6 * 32 * 33 + (size_t)N * (D | 1)) * sizeof(double);
     const size_t flag_bytes = (((size_t)T * 44 * 4) + 15) & ~(size_t)15;
     const size_t need = flag_bytes + (size_t)T * N * 8 + (size_t)T * 64 * 8;
-    const bool take = g_blocked_fit_path == 2 ? parts >= 1 : (g_blocked_fit_path == 0 && parts >= 2);
+    // by shape (dev_coop_time.py, profiles/r03_notes.md): three or more workgroups per task always pay; two only while a workgroup's eight
+    // or fewer block columns leave it time to keep up with the diagonal chain (N <= 320)
+    const bool take = g_blocked_fit_path == 2 ? parts >= 1 : (g_blocked_fit_path == 0 && (parts >= 3 || (parts == 2 && nbc <= 10)));
     if (take && D <= 16 && lds_coop <= 160 * 1024 && need <= (size_t)workspace_bytes) {
       hipStream_t st = (hipStream_t)stream;
       if ((e = hipMemsetAsync(ws, 0, flag_bytes, st)) != hipSuccess) { set_error("hipMemsetAsync(coop flags)", e); return SCAML_E_LAUNCH; }

@@ -139,6 +139,8 @@ def _load() -> ctypes.CDLL:
     lib.scaml_debug_target_fit_path.argtypes = [c_int]
     lib.scaml_debug_blocked_fit_path.restype = c_int
     lib.scaml_debug_blocked_fit_path.argtypes = [c_int]
+    lib.scaml_debug_coop_far.restype = c_int
+    lib.scaml_debug_coop_far.argtypes = [c_int]
     lib.scaml_debug_force_two_launch_grad.restype = c_int
     lib.scaml_debug_force_two_launch_grad.argtypes = [c_int]
     return lib

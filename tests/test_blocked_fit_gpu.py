@@ -1,5 +1,7 @@
-"""The blocked fit for 256 < N <= 512 points per task (scaml_gp_fit_blocked_f64, csrc/gp_fit_blocked.hip): BASELINE configs[4]'s
-source tasks (scamlgp/benchmarking/configurations/hartmann6_ablation_num_points_per_task.py:17-18).  Parity against the oracle
+"""The blocked fit for 256 < N <= 512 points per task (scaml_gp_fit_blocked_f64): BASELINE configs[4]'s source tasks
+(scamlgp/benchmarking/configurations/hartmann6_ablation_num_points_per_task.py:17-18).  Every test runs twice: through the 2 x 2
+sequence of launches (csrc/gp_fit_blocked.hip, one CU per task) and through the one-launch kernel that gives a task several CUs
+(csrc/gp_fit_coop.hip; what small stacks take by default -- tests/test_coop_fit_gpu.py has the tests specific to it).  Parity against the oracle
 (1e-4 alpha, 1e-3 MLL; the kernels are far inside), against the composition of library launches it replaces, the argument
 contract of the C entry point, the jitter rounds on the device, and stream capture (no host synchronisation inside)."""
 import ctypes
@@ -12,6 +14,13 @@ from oracle import gp_oracle as O
 from scamlgp_amd import _lib, ops, synthetic
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["sequence of launches", "one launch"])
+def blocked_path(request, device):
+    was = _lib.lib.scaml_debug_blocked_fit_path(1 if request.param == "sequence of launches" else 2)
+    yield request.param
+    _lib.lib.scaml_debug_blocked_fit_path(was)
 
 
 def _stack(T, N, D, seed):
