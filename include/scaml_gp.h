@@ -80,10 +80,14 @@ int scaml_gp_fit_fused_f64(const double* X, const double* y, const double* theta
 /*
  * (3b) The same fit for scaml_fit_max_n() < N <= scaml_fit_blocked_max_n() points per task (the 512-point source
  * tasks of scamlgp/benchmarking/configurations/hartmann6_ablation_num_points_per_task.py:17-18, fitted in the
- * reference by the same scamlgp/model.py:176-188 / scamlgp/utils.py:171-177 chain): a 2 x 2 block factorisation
- * enqueued as one sequence of launches -- fused fit of the first 256 points in place, L21 = (L11^-1 K12)^T by column
- * strips, Schur complement, fused factorisation of the Schur complement in place, alpha / MLL assembly -- with no
- * host synchronisation and nothing but this library's kernels on the stream.  Arguments, outputs and the jitter
+ * reference by the same scamlgp/model.py:176-188 / scamlgp/utils.py:171-177 chain), with no host synchronisation
+ * and nothing but this library's kernels (and one memset of a few words) on the stream.  Two implementations behind
+ * the one entry point, chosen by shape: while the stack leaves CUs idle (3 T <= #CUs; 2 T <= #CUs for N <= 320;
+ * D <= 16) ONE launch in which up to eight workgroups share a task (csrc/gp_fit_coop.hip); otherwise a 2 x 2 block
+ * factorisation enqueued as one sequence of launches -- fused fit of the first 256 points in place, L21 =
+ * (L11^-1 K12)^T by column strips, Schur complement, fused factorisation of the Schur complement in place, alpha /
+ * MLL assembly.  Same results to rounding (tests/test_blocked_fit_gpu.py runs every test through both; info[t] = -1:
+ * the one-launch kernel gave a task up after a bounded wait, which no correct run does).  Arguments, outputs and the jitter
  * ladder (one value for the whole matrix of a failing task: 0, 1e-8, 1e-7, 1e-6) are those of
  * scaml_gp_fit_fused_f64; info[t] = k > 0 counts pivots over the full matrix.  Requirements: N a multiple of 16,
  * D <= scaml_fit_blocked_max_d(); L, alpha, info and Linv_diag must be given (the later launches read the earlier
