@@ -288,6 +288,44 @@ __device__ __forceinline__ void cf_accumulate_v(d4_t& r0, d4_t& r1, __amdgpu_buf
   cf_settle(r1);
 }
 
+// Two tiles with the same B rows (the same tile position in two consecutive block rows) in ONE pipeline: B is loaded once, and the two
+// tiles share the pipeline's start-up round trip (an even column's first chunk has two block rows to finish while the diagonal block is
+// being factored; one after the other they do not fit into that time).
+struct CfOpsA2 {
+  cf_u4 a0, a1, c0, c1, b0, b1;
+};
+__device__ __forceinline__ CfOpsA2 cf_loada2(__amdgpu_buffer_rsrc_t rs, unsigned baseA, unsigned baseC, unsigned baseB, int s, int s_hi) {
+  const unsigned off = s < s_hi ? 128u * (unsigned)s : 0xC0000000u;
+  CfOpsA2 o;
+  o.a0 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseA + off, 0, 16);
+  o.a1 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseA + off + 16, 0, 16);
+  o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseC + off, 0, 16);
+  o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseC + off + 16, 0, 16);
+  o.b0 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + off, 0, 16);
+  o.b1 = __builtin_amdgcn_raw_buffer_load_b128(rs, baseB + off + 16, 0, 16);
+  return o;
+}
+__device__ __forceinline__ void cf_mmaa2(const CfOpsA2& o, d4_t& r0, d4_t& r1) {
+  r0 = cf_mma(CfOps{o.a0, o.a1, o.b0, o.b1}, r0);
+  r1 = cf_mma(CfOps{o.c0, o.c1, o.b0, o.b1}, r1);
+}
+__device__ __forceinline__ void cf_accumulate_a2(d4_t& r0, d4_t& r1, __amdgpu_buffer_rsrc_t rs, int N, int rowA, int rowC, int rowB, int c_lo, int c_hi, int lc, int lq) {
+  const unsigned baseA = (unsigned)(((size_t)(rowA + lc) * N + 4 * lq) * 8), baseC = (unsigned)(((size_t)(rowC + lc) * N + 4 * lq) * 8);
+  const unsigned baseB = (unsigned)(((size_t)(rowB + lc) * N + 4 * lq) * 8);
+  const int s_hi = 2 * c_hi;
+  CfOpsA2 b0 = cf_loada2(rs, baseA, baseC, baseB, 2 * c_lo, s_hi), b1 = cf_loada2(rs, baseA, baseC, baseB, 2 * c_lo + 1, s_hi), b2;
+  for (int s = 2 * c_lo; s < s_hi; s += 3) {
+    b2 = cf_loada2(rs, baseA, baseC, baseB, s + 2, s_hi);
+    cf_mmaa2(b0, r0, r1);
+    b0 = cf_loada2(rs, baseA, baseC, baseB, s + 3, s_hi);
+    if (s + 1 < s_hi) cf_mmaa2(b1, r0, r1);
+    b1 = cf_loada2(rs, baseA, baseC, baseB, s + 4, s_hi);
+    if (s + 2 < s_hi) cf_mmaa2(b2, r0, r1);
+  }
+  cf_settle(r0);
+  cf_settle(r1);
+}
+
 template <int KIND>
 __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -396,7 +434,8 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
     // the first chunk behind it).  Their sums over the columns c <= j - 2 do not depend on the column the workgroup is waiting for,
     // so they are taken in the waiting time -- one bounded piece between two polls, so that the awaited tile is never kept waiting for
     // long; summed on demand instead, those tiles trail the diagonal chain by more with every column.
-    // mode 0: tile (ti, tj) of the block row; 1: the same with A and B the same rows (diagonal tiles); 2: no tile, L_j,0:j v (-> acc, accb).
+    // mode 0: tile (ti, tj) of the block row; 1: the same with A and B the same rows (diagonal tiles); 2: no tile, L_j,0:j v (-> acc, rv1);
+    // 3: the tiles (ti, tj) of the block rows `row` and `row + 1` together (-> acc, rv1).
     struct Slot {
       d4_t acc;
       int row, mode, done;
@@ -421,13 +460,15 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
         for (int k = 0; k < 4; ++k) {
           Slot& sl = k == 0 ? s0 : (k == 1 ? s1 : (k == 2 ? s2 : s3));
           if (k < target || !sl.on || sl.done >= j || moved) continue;
-          const unsigned long long m = __ballot(lane >= j || (tag_ok && cnt >= sl.row - lane + 1));
+          const unsigned long long m = __ballot(lane >= j || (tag_ok && cnt >= sl.row + (sl.mode == 3 ? 1 : 0) - lane + 1));
           int ready = m == ~0ull ? j : __builtin_ctzll(~m);
           if (ready > j) ready = j;
           if (ready > sl.done) {
             if (k != target && ready > sl.done + 2) ready = sl.done + 2;
             if (sl.mode == 2) {
               cf_accumulate_v(sl.acc, rv1, rsV, rsL, N, 32 * j, sl.done, ready, lc, lq);
+            } else if (sl.mode == 3) {
+              cf_accumulate_a2(sl.acc, rv1, rsL, N, 32 * sl.row + 16 * ti, 32 * (sl.row + 1) + 16 * ti, 32 * j + 16 * tj, sl.done, ready, lc, lq);
             } else if (sl.mode == 1) {
               sl.acc = cf_accumulate<true>(sl.acc, rsL, rsL, N, 32 * sl.row + 16 * ti, 32 * j + 16 * tj, sl.done, ready, lc, lq);
             } else {
@@ -508,12 +549,12 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       const int nb0 = NB - j < want0 ? NB - j : want0;
       const d4_t z4 = {0.0, 0.0, 0.0, 0.0};
       // slot 0: diagonal block (tiles (0,0), (1,0), (1,1); the fourth wave: L_j,0:j v) / block row j + 1; slot 1: block row j + 2 (summed
-      // by waves 4-7 while wave 0 factors the diagonal block); slot 2: in an even column block row j + 3 (the same waves, right behind),
-      // in an odd one this wave's tile of the first chunk behind (block rows j + 3, j + 4)
+      // by waves 4-7 while wave 0 factors the diagonal block); in an even column together with block row j + 3 (mode 3);
+      // slot 2 (odd columns): this wave's tile of the first chunk behind (block rows j + 3, j + 4)
       const bool four = nb0 > 3;
       Slot s0{z4, j + wb, wb == 0 ? (wq == 1 ? 2 : (wq == 2 ? 0 : 1)) : 0, 0, wb == 0 || nb0 > 1};
-      Slot s1{z4, j + 2, 0, 0, wb == 1 && nb0 > 2};
-      Slot s2{z4, (j & 1) ? j + 3 + wb : j + 3, 0, 0, (j & 1) ? (j + 3 + wb < NB) : (wb == 1 && four)};
+      Slot s1{z4, j + 2, four ? 3 : 0, 0, wb == 1 && nb0 > 2};
+      Slot s2{z4, j + 3 + wb, 0, 0, (j & 1) && j + 3 + wb < NB};
       // slot 3: this wave's tile of the next chunk behind those (block rows j + 5, j + 6 in an odd column, j + 4, j + 5 in an even one)
       const int row3 = ((j & 1) ? j + 5 : j + 4) + wb;
       Slot s3{z4, row3, 0, 0, row3 < NB};
@@ -552,10 +593,14 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
         if (s1.on) {                             // (block row j + 2, during the factorisation of the diagonal block)
           const d4_t kt1 = kvals(j, s1.row);
           advance(j, s0, s1, s2, s3, 1);
-          if (!gone) put(s1, kt1, Cb + 2 * CF_BS);
-          if (!gone && four) {
-            advance(j, s0, s1, s2, s3, 2);
-            if (!gone) put(s2, kt2, Cb + 3 * CF_BS);
+          if (!gone) {
+            if (four) {
+              const d4_t kt1b = kvals(j, s1.row + 1);
+              cf_settle(rv1);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) Cb[3 * CF_BS + (16 * ti + lq + 4 * g) * CF_BP + 16 * tj + lc] = kt1b[g] - rv1[g];
+            }
+            put(s1, kt1, Cb + 2 * CF_BS);
           }
         }
       }
