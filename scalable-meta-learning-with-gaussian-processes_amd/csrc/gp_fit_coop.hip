@@ -752,29 +752,48 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
       //  one is used)
       CF_FSTAMP(0);
       const int nb16 = N / 16;
-      double* ab = tv;      // [16]
-      double* Wl = Dg;      // [256] W_b of the current step (row-major)
-      // Thread t < 256 owns the columns 2 t, 2 t + 1 of the pushes (N <= 512); the 16 rows of L of a step come as 16-byte sc1 buffer
-      // loads, CF_FD steps ahead (they depend on nothing computed here; a step is ~150 ns of arithmetic, a load ~1 us away), W_b as one
-      // element per thread, put into LDS a step ahead of its use.  No load is conditional (a conditional load is a branch, and the
-      // compiler waits for every load in flight at its join): what a thread does not need gets an offset beyond the descriptor's end
-      // and loads as zero.  The upper four waves only take part in the barriers.
+      // Row-push form by 16-row blocks, last to first: alpha_b = W_b^T v_b, then v_k -= sum_r L[16 b + r][k] alpha_b[r] for k < 16 b.
+      // Thread t < 256 owns the columns 2 t, 2 t + 1 of the pushes (N <= 512).  The 16 rows of L of a step come as 16-byte sc1 buffer
+      // loads CF_FD steps ahead (they depend on nothing computed here; a step is ~150 ns of arithmetic, a load ~1 us away); all the W_b
+      // are fetched into LDS up front (64 KB: the chunk buffers and the staged points are free by now).  No load is conditional (a
+      // conditional load is a branch, and the compiler waits for every load in flight at its join): what a thread does not need gets
+      // an offset beyond the descriptor's end and loads as zero.  ONE barrier per step: the wave whose threads own the columns of block
+      // b - 1 forms alpha_{b-1} right behind its own push of step b (its v_{b-1} is final then), into the other of two alpha buffers.
+      double* Wall = Cb;                        // [nb16][256]
+      double* vs2 = Wall + (size_t)nb16 * 256;  // [N]: v moves behind the W blocks
+      double* abuf = tv;                        // [2][16]
       constexpr int CF_FD = 3;
       cf_d2 lr[CF_FD][16];
-      double wq4[CF_FD];
       const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(Wg, 0, nb16 * 256 * 8, 0x00020000);
       const bool loader = tid < 256;
-      auto fetch = [&](int b, cf_d2* l, double& w) {
+      auto fetch = [&](int b, cf_d2* l) {
         const unsigned base = (b >= 0 && 2 * tid < 16 * b) ? (unsigned)(((size_t)(16 * b) * N + 2 * tid) * 8) : 0xC0000000u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) l[r] = __builtin_bit_cast(cf_d2, __builtin_amdgcn_raw_buffer_load_b128(rsL, base + (unsigned)(r * N * 8), 0, 16));
-        typedef unsigned cf_u2 __attribute__((ext_vector_type(2)));
-        w = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsW, b >= 0 ? (unsigned)((b * 256 + tid) * 8) : 0xC0000000u, 0, 16));
       };
       if (loader) {
 #pragma unroll
-        for (int u = 0; u < CF_FD; ++u) fetch(nb16 - 1 - u, lr[u], wq4[u]);
-        Wl[tid] = wq4[0];
+        for (int u = 0; u < CF_FD; ++u) fetch(nb16 - 1 - u, lr[u]);
+      }
+      {
+        // v out of the chunk buffer (the W blocks go there), then every W block
+        double vkeep = tid < N ? vs[tid] : 0.0;
+        __syncthreads();
+        if (tid < N) vs2[tid] = vkeep;
+        for (int e = tid; e < nb16 * 128; e += blockDim.x) {
+          const cf_d2 w2 = __builtin_bit_cast(cf_d2, __builtin_amdgcn_raw_buffer_load_b128(rsW, (unsigned)(e * 16), 0, 16));
+          Wall[2 * e] = w2[0];
+          Wall[2 * e + 1] = w2[1];
+        }
+      }
+      cf_lds_barrier();
+      if (tid < 16) {
+        const int b = nb16 - 1;
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a = __builtin_fma(Wall[b * 256 + r * 16 + tid], vs2[16 * b + r], a);   // (W_b^T v_b)[tid]
+        abuf[(b & 1) * 16 + tid] = a;
+        if (16 * b + tid < n) p.alpha[(size_t)task * N + 16 * b + tid] = a;
       }
       cf_lds_barrier();
       CF_FSTAMP(1);
@@ -784,28 +803,28 @@ __global__ __launch_bounds__(512) void gp_fit_coop_kernel(CoopFitParams p) {
         for (int u = 0; u < CF_FD; ++u) {
           const int b = b0 - u;
           if (b >= 0) {
-            if (tid < 16) {
-              double a = 0.0;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) a = __builtin_fma(Wl[r * 16 + tid], vs[16 * b + r], a);   // (W_b^T v_b)[tid]
-              ab[tid] = a;
-              if (16 * b + tid < n) p.alpha[(size_t)task * N + 16 * b + tid] = a;
-            }
-            cf_lds_barrier();
             if (loader) {
               if (2 * tid < 16 * b) {
-                double sa = vs[2 * tid], sb = vs[2 * tid + 1];
+                const double* ab = abuf + (b & 1) * 16;
+                double sa = vs2[2 * tid], sb = vs2[2 * tid + 1];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                   const double ar = ab[r];
                   sa = __builtin_fma(-lr[u][r][0], ar, sa);
                   sb = __builtin_fma(-lr[u][r][1], ar, sb);
                 }
-                vs[2 * tid] = sa;
-                vs[2 * tid + 1] = sb;
+                vs2[2 * tid] = sa;
+                vs2[2 * tid + 1] = sb;
               }
-              Wl[tid] = wq4[(u + 1) % CF_FD];   // W of the next step
-              fetch(b - CF_FD, lr[u], wq4[u]);
+              fetch(b - CF_FD, lr[u]);
+              if (b > 0 && wave == ((b - 1) >> 3) && lane < 16) {
+                // (same wave as the eight threads that have just written v_{b-1}: LDS operations of a wave execute in order)
+                double a = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a = __builtin_fma(Wall[(b - 1) * 256 + r * 16 + lane], vs2[16 * (b - 1) + r], a);
+                abuf[((b - 1) & 1) * 16 + lane] = a;
+                if (16 * (b - 1) + lane < n) p.alpha[(size_t)task * N + 16 * (b - 1) + lane] = a;
+              }
             }
             cf_lds_barrier();
           }
