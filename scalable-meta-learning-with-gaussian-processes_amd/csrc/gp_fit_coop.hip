@@ -71,6 +71,70 @@ __device__ __forceinline__ double cf_rsqrt(double d) {
 // l & 15 of L and column l & 15 of W = L^-1; pivots and multipliers travel by v_readlane (csrc/gp_target_fit.hip has the same sweep).
 // L (zeros above the diagonal) -> Ld, W -> Wd.  Returns 0, or 1 + the index of the first pivot that is not positive.
 typedef __attribute__((address_space(3))) double cf_lds_double;
+
+// The pivot sweep's building blocks.  The multipliers L[b][cc] of a pivot step sit one per lane (lane b of every 16-lane row: the four
+// rows are mirrors); every lane needs all of them.  gfx950's 64-bit DPP takes exactly that pattern as an operand modifier --
+// row_newbcast:b = lane b of the row, to every lane of the row -- so one v_fmac_f64_dpp does what two v_readlane_b32, their SGPR hazard
+// slot and an FMA did: ~840 instructions per sweep instead of ~2,300.  (Inline asm: hipcc has no builtin for the 64-bit form; the
+// s_nop covers the two wait states a DPP read needs behind the VALU write of its source, which the compiler's hazard recogniser does
+// not see inside an asm.)
+template <int B>
+__device__ __forceinline__ void cf_upd(double (&row)[16], double (&sp)[16], double x, double nx, double wcc) {
+  if constexpr (B < 16) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(row[B]) : "v"(x), "v"(nx), "n"(B));
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(sp[B]) : "v"(x), "v"(wcc), "n"(B));
+  }
+}
+#define CF_FENCE(v) asm volatile("" : "+v"(v))
+// Pivot step CC, entered with rsq = 1 / sqrt(pivot CC); leaves with the next pivot's.  The reciprocal square root of the NEXT pivot is a
+// chain of ~25 dependent instructions and needs nothing but row[CC + 1] after this step's first update: its pieces are placed between
+// the remaining updates (empty asm fences pin every piece between two of them), where an in-order wave would otherwise wait for one
+// result after the other before it even starts on the updates.
+template <int CC>
+__device__ __forceinline__ void cf_step(double (&row)[16], double (&sp)[16], double (&wv)[16], double& rsq, int& bad, int lc) {
+  const double x = row[CC] * rsq;   // lane CC: pivot / sqrt(pivot)
+  row[CC] = x;
+  const double wcc = ((lc == CC ? 1.0 : 0.0) - sp[CC]) * rsq;
+  wv[CC] = wcc;
+  const double nx = -x;
+  asm volatile("s_nop 1" ::"v"(x), "v"(nx), "v"(wcc));
+  cf_upd<CC + 1>(row, sp, x, nx, wcc);
+  if constexpr (CC < 15) {
+    double pv;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(pv) : "v"(row[CC + 1]), "n"(CC + 1));
+    if (!(pv > 0.0) && bad == 0) bad = CC + 2;
+    cf_upd<CC + 2>(row, sp, x, nx, wcc);
+    const int h = __builtin_amdgcn_frexp_exp(pv) >> 1;
+    double m = __builtin_ldexp(pv, -2 * h);   // in [0.5, 2): the f32-seeded step works on it, whatever the pivot's exponent
+    CF_FENCE(m);
+    cf_upd<CC + 3>(row, sp, x, nx, wcc);
+    double y = (double)__builtin_amdgcn_rsqf((float)m);
+    CF_FENCE(y);
+    cf_upd<CC + 4>(row, sp, x, nx, wcc);
+    double e = __builtin_fma(-(m * y), y, 1.0);
+    CF_FENCE(e);
+    cf_upd<CC + 5>(row, sp, x, nx, wcc);
+    double pp = __builtin_fma(e, 0.375, 0.5), ye = y * e;
+    CF_FENCE(pp);
+    CF_FENCE(ye);
+    cf_upd<CC + 6>(row, sp, x, nx, wcc);
+    rsq = __builtin_ldexp(__builtin_fma(ye, pp, y), -h);
+    CF_FENCE(rsq);
+    cf_upd<CC + 7>(row, sp, x, nx, wcc);
+    cf_upd<CC + 8>(row, sp, x, nx, wcc);
+    cf_upd<CC + 9>(row, sp, x, nx, wcc);
+    cf_upd<CC + 10>(row, sp, x, nx, wcc);
+    cf_upd<CC + 11>(row, sp, x, nx, wcc);
+    cf_upd<CC + 12>(row, sp, x, nx, wcc);
+    cf_upd<CC + 13>(row, sp, x, nx, wcc);
+    cf_upd<CC + 14>(row, sp, x, nx, wcc);
+    cf_upd<CC + 15>(row, sp, x, nx, wcc);
+  }
+}
+
+// Cholesky factor and inverse of the 16 x 16 block at src (LDS, pitch CF_BP) by ONE wave: lane l (and its mirrors l + 16 m) is row
+// l & 15 of L and column l & 15 of W = L^-1 (csrc/gp_target_fit.hip has the same sweep on v_readlane).
+// L (zeros above the diagonal) -> Ld, W -> Wd.  Returns 0, or 1 + the index of the first pivot that is not positive.
 #ifndef CF_SWEEP_INLINE
 __device__ __attribute__((noinline)) int cf_potf2_16(const cf_lds_double* src, cf_lds_double* Ld, cf_lds_double* Wd, int lane) {
 #else
@@ -84,47 +148,29 @@ __device__ __forceinline__ int cf_potf2_16(const cf_lds_double* src, cf_lds_doub
     sp[b] = 0.0;
   }
   int bad = 0;
-  // The multipliers L[b][cc] of a pivot step sit one per lane (lane b of every 16-lane row: the four rows are mirrors); every lane needs
-  // all of them.  gfx950's 64-bit DPP takes exactly that pattern as an operand modifier -- row_newbcast:b = lane b of the row, to
-  // every lane of the row -- so one v_fmac_f64_dpp does what two v_readlane_b32, their SGPR hazard slot and an FMA did: the sweep is
-  // ~900 instructions instead of ~2,300 (2.8 us -> see profiles/r03_notes.md).  (Inline asm: hipcc has no builtin for the 64-bit
-  // form; the s_nop covers the two wait states a DPP read needs behind the VALU write of its source, which the compiler's hazard
-  // recogniser does not see inside an asm.)
-#define CF_BCAST(dst, src, B) asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" #B " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(src))
-#define CF_FMAC_B(acc, xs, y, B) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #B " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(xs), "v"(y))
-#define CF_STEP(CC)                                                                          \
-  {                                                                                          \
-    double pv;                                                                               \
-    CF_BCAST(pv, row[CC], CC);                                                               \
-    if (!(pv > 0.0) && bad == 0) bad = CC + 1;                                               \
-    const double rsq = cf_rsqrt(pv);                                                         \
-    const double x = row[CC] * rsq;   /* lane CC: pv / sqrt(pv) */                           \
-    row[CC] = x;                                                                             \
-    const double wcc = ((lc == CC ? 1.0 : 0.0) - sp[CC]) * rsq;                              \
-    wv[CC] = wcc;                                                                            \
-    const double nx = -x;                                                                    \
-    asm volatile("s_nop 1" ::"v"(x), "v"(nx), "v"(wcc));                                     \
-    CF_TAIL_##CC                                                                             \
+  double rsq;
+  {
+    double pv;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(pv) : "v"(row[0]));
+    if (!(pv > 0.0)) bad = 1;
+    rsq = cf_rsqrt(pv);
   }
-#define CF_UPD(B) CF_FMAC_B(row[B], x, nx, B); CF_FMAC_B(sp[B], x, wcc, B);
-#define CF_TAIL_15
-#define CF_TAIL_14 CF_UPD(15)
-#define CF_TAIL_13 CF_UPD(14) CF_TAIL_14
-#define CF_TAIL_12 CF_UPD(13) CF_TAIL_13
-#define CF_TAIL_11 CF_UPD(12) CF_TAIL_12
-#define CF_TAIL_10 CF_UPD(11) CF_TAIL_11
-#define CF_TAIL_9 CF_UPD(10) CF_TAIL_10
-#define CF_TAIL_8 CF_UPD(9) CF_TAIL_9
-#define CF_TAIL_7 CF_UPD(8) CF_TAIL_8
-#define CF_TAIL_6 CF_UPD(7) CF_TAIL_7
-#define CF_TAIL_5 CF_UPD(6) CF_TAIL_6
-#define CF_TAIL_4 CF_UPD(5) CF_TAIL_5
-#define CF_TAIL_3 CF_UPD(4) CF_TAIL_4
-#define CF_TAIL_2 CF_UPD(3) CF_TAIL_3
-#define CF_TAIL_1 CF_UPD(2) CF_TAIL_2
-#define CF_TAIL_0 CF_UPD(1) CF_TAIL_1
-  CF_STEP(0) CF_STEP(1) CF_STEP(2) CF_STEP(3) CF_STEP(4) CF_STEP(5) CF_STEP(6) CF_STEP(7)
-  CF_STEP(8) CF_STEP(9) CF_STEP(10) CF_STEP(11) CF_STEP(12) CF_STEP(13) CF_STEP(14) CF_STEP(15)
+  cf_step<0>(row, sp, wv, rsq, bad, lc);
+  cf_step<1>(row, sp, wv, rsq, bad, lc);
+  cf_step<2>(row, sp, wv, rsq, bad, lc);
+  cf_step<3>(row, sp, wv, rsq, bad, lc);
+  cf_step<4>(row, sp, wv, rsq, bad, lc);
+  cf_step<5>(row, sp, wv, rsq, bad, lc);
+  cf_step<6>(row, sp, wv, rsq, bad, lc);
+  cf_step<7>(row, sp, wv, rsq, bad, lc);
+  cf_step<8>(row, sp, wv, rsq, bad, lc);
+  cf_step<9>(row, sp, wv, rsq, bad, lc);
+  cf_step<10>(row, sp, wv, rsq, bad, lc);
+  cf_step<11>(row, sp, wv, rsq, bad, lc);
+  cf_step<12>(row, sp, wv, rsq, bad, lc);
+  cf_step<13>(row, sp, wv, rsq, bad, lc);
+  cf_step<14>(row, sp, wv, rsq, bad, lc);
+  cf_step<15>(row, sp, wv, rsq, bad, lc);
   bad = __builtin_amdgcn_readfirstlane(bad);
   if (lane < 16) {
 #pragma unroll
