@@ -127,9 +127,9 @@ _FORCE_COMPOSED_TWO_BLOCK = False   # tests / A-B timing: route 256 < N <= 512 t
 
 def _gp_fit_blocked(X, y, theta, kind, n_points, jitter, zero_upper, retry) -> Dict[str, torch.Tensor]:
     """Fused fit for scaml_fit_max_n() < N <= scaml_fit_blocked_max_n() (the N = 512 source tasks of BASELINE
-    configs[4]): ``scaml_gp_fit_blocked_f64`` -- a 2 x 2 block factorisation enqueued as one sequence of the
-    library's launches (csrc/gp_fit_blocked.hip), jitter ladder included, without a host synchronisation or a
-    framework op in between.  L and Linv_diag are always produced (the later launches read them)."""
+    configs[4]): ``scaml_gp_fit_blocked_f64`` -- by shape, ONE launch with several CUs per task (csrc/gp_fit_coop.hip; stacks that
+    leave CUs idle) or a 2 x 2 block factorisation enqueued as one sequence of the library's launches (csrc/gp_fit_blocked.hip);
+    jitter ladder included, without a host synchronisation or a framework op in between.  L and Linv_diag are always produced."""
     T, N, D = X.shape
     dev = X.device
     with torch.cuda.device(dev):
@@ -789,6 +789,12 @@ def target_fit(prob: TargetFitProblem, z0: torch.Tensor, max_iter: int = 200, hi
 
 def raise_if_not_psd(info: torch.Tensor) -> None:
     """Host-side check of the per-task status (one device->host sync)."""
+    if bool((info < 0).any()):
+        # only the several-CUs-per-task fit reports this (csrc/gp_fit_coop.hip): its workgroups wait for each other inside one launch, with
+        # bounded polls; a task given up after ~0.5 s means its workgroups were not resident together -- another launch (a second process
+        # or stream on this GPU) held the CUs while waiting itself.  SCAML_BLOCKED_FIT_PATH=1 keeps to the sequence of launches.
+        raise RuntimeError("scaml_gp_fit_blocked_f64: the one-launch fit timed out waiting for its own workgroups (the GPU is shared with "
+                           "another long-running launch?); set SCAML_BLOCKED_FIT_PATH=1 to use the sequence of launches")
     bad = torch.nonzero(info > 0).flatten()
     if bad.numel():
         raise NotPSDError(
