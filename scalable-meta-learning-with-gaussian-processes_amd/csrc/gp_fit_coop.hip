@@ -36,7 +36,7 @@ typedef double cf_d2 __attribute__((ext_vector_type(2)));
 #endif
 constexpr int CF_BP = 33;               // pitch of the 32 x 32 blocks in LDS
 constexpr int CF_BS = 32 * CF_BP;
-constexpr int CF_SPIN_LIMIT = 400000;   // polls (~1 us each) before a workgroup gives the task up: a protocol error, never a wait
+constexpr int CF_SPIN_LIMIT = 4000000;  // polls (~1 us each: ~4 s) before a workgroup gives the task up: a protocol error, never a wait
 constexpr unsigned CF_DEAD = 255u;      // failure count that stops every attempt (time-out)
 
 // developer build (-DCF_STAMPS): 100 MHz wall-clock stamps of task 0, thread 0 of every part, into the workspace behind `part`

@@ -791,7 +791,7 @@ def raise_if_not_psd(info: torch.Tensor) -> None:
     """Host-side check of the per-task status (one device->host sync)."""
     if bool((info < 0).any()):
         # only the several-CUs-per-task fit reports this (csrc/gp_fit_coop.hip): its workgroups wait for each other inside one launch, with
-        # bounded polls; a task given up after ~0.5 s means its workgroups were not resident together -- another launch (a second process
+        # bounded polls; a task given up after ~4 s means its workgroups were not resident together -- another launch (a second process
         # or stream on this GPU) held the CUs while waiting itself.  SCAML_BLOCKED_FIT_PATH=1 keeps to the sequence of launches.
         raise RuntimeError("scaml_gp_fit_blocked_f64: the one-launch fit timed out waiting for its own workgroups (the GPU is shared with "
                            "another long-running launch?); set SCAML_BLOCKED_FIT_PATH=1 to use the sequence of launches")
