@@ -45,53 +45,37 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
     for (int r = lq; r < 16 * strip && r < N; r += 4)
       if (qc < N) Og[(size_t)r * N + qc] = 0.0;
   }
-  // acc -= sum_{strip <= j < kb} L[kb, j] V_j.  One workgroup per task at T >= 256 means ONE wave per SIMD: nobody
-  // hides this wave's load latency, so the L row segments are fetched four tiles ahead -- across the end of a block
-  // row into the first tiles of the next -- and W_kb one block ahead (subst_accumulate looks one tile ahead).
-  LRowSeg q[4];
-  auto fetch4 = [&](int kbr, int jf) {   // tiles jf .. jf + 3 of block row kbr (zeros past the diagonal / the matrix)
-    const int arow = 16 * kbr + lc;
-    const bool arow_ok = kbr < NB && arow < n;
-    const double* Lrow = Lg + (size_t)(arow < N ? arow : 0) * N;
-    const bool rows_in = 16 * kbr + 16 <= n;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = jf + u;
-      if (kbr < NB && j < kbr) {
-        q[u] = load_lrow_seg(Lrow, 16 * j + 4 * lq, rows_in && (N & 1) == 0 && 16 * j + 16 <= n, arow_ok, n);
-      } else {
-        q[u].a[0] = q[u].a[1] = q[u].a[2] = q[u].a[3] = 0.0;
-      }
+  // acc -= sum_{strip <= j < kb} L[kb, j] V_j.  One workgroup per task at T >= 256 means ONE wave per SIMD: nobody hides this wave's load
+  // latency, so the L row segments are fetched EIGHT tiles ahead in eight buffers that rotate in place over the FLAT sequence of (block
+  // row, tile) pairs of the strip -- across the end of a block row into the first tiles of the next -- and W_kb one block ahead.
+  // Round 3: unconditional 16-byte BUFFER loads (rows past n_t and the end of the sequence get an offset beyond the descriptor's end
+  // and load as zeros) and no copy of the buffers: before, the four segments were copied to a second set at the top of every group of
+  // four products, and the compiler waited there for the loads it had issued one group earlier -- a product is 256 cycles, an L2 round
+  // trip 1,000-2,000.
+  typedef unsigned lv_u4 __attribute__((ext_vector_type(4)));
+  typedef double lv_d2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Lg), 0, n * N * 8, 0x00020000);
+  int ckb = strip + 1, cj = strip;   // load cursor
+  auto next_load = [&]() {
+    const unsigned off = ckb < NB ? (unsigned)(((size_t)(16 * ckb + lc) * N + 16 * cj + 4 * lq) * 8) : 0xC0000000u;
+    const lv_d2 x = __builtin_bit_cast(lv_d2, __builtin_amdgcn_raw_buffer_load_b128(rsL, off, 0, 0));
+    const lv_d2 y = __builtin_bit_cast(lv_d2, __builtin_amdgcn_raw_buffer_load_b128(rsL, off + 16, 0, 0));
+    if (++cj >= ckb) {
+      ++ckb;
+      cj = strip;
     }
+    LRowSeg t;
+    t.a[0] = x[0]; t.a[1] = x[1]; t.a[2] = y[0]; t.a[3] = y[1];
+    return t;
   };
   double wn[4];
   auto fetch_w = [&](int kbn) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) wn[m] = kbn < NB ? Wg[(size_t)kbn * 256 + lc * 16 + lq + 4 * m] : 0.0;
   };
-  fetch_w(strip);
-  fetch4(strip + 1, strip);
-  for (int kb = strip; kb < NB; ++kb) {
-    d4_t acc;
-    double wc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { acc[g] = (kb == strip && lc == lq + 4 * g) ? 1.0 : 0.0; wc[g] = wn[g]; }
-    fetch_w(kb + 1);
-    for (int j0 = strip; j0 < kb; j0 += 4) {
-      LRowSeg cur[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cur[u] = q[u];
-      if (j0 + 4 < kb) fetch4(kb, j0 + 4); else fetch4(kb + 1, strip);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int j = j0 + u;
-        if (j < kb) {   // (the strip's rows of later blocks are not written yet: no reading them, even times zero)
-          const double* vb = Vs + (16 * j + lq) * 16 + lc;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[u].a[m], vb[4 * m * 16], acc, 0, 0, 1);
-        }
-      }
-    }
+  d4_t acc;
+  double wc[4];
+  auto finish_row = [&](int kb) {   // V_kb = W_kb acc -> the wave's strip in LDS (operand position) and the output
     d4_t v = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < 4; ++m) v = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[m], acc[m], v, 0, 0, 0);
@@ -101,6 +85,43 @@ __global__ __launch_bounds__(256) void gp_linv_kernel(LinvParams p) {
       Vs[(16 * kb + strip_row(lq, g)) * 16 + lc] = v[g];
       if (row < N && qc < N) Og[(size_t)row * N + qc] = v[g];
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { acc[g] = 0.0; wc[g] = wn[g]; }
+    fetch_w(kb + 2);
+  };
+  fetch_w(strip);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { acc[g] = (lc == lq + 4 * g) ? 1.0 : 0.0; wc[g] = wn[g]; }
+  fetch_w(strip + 1);
+  LRowSeg q0 = next_load(), q1 = next_load(), q2 = next_load(), q3 = next_load(), q4 = next_load(), q5 = next_load(), q6 = next_load(), q7 = next_load();
+  finish_row(strip);   // (block row `strip`: no products, V = W_strip)
+  {
+    int kb = strip + 1, j = strip;
+    auto use = [&](const LRowSeg& c) {
+      const double* vb = Vs + (16 * j + lq) * 16 + lc;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a[m], vb[4 * m * 16], acc, 0, 0, 1);
+    };
+#define SCAML_LINV_STEP(q)        \
+    use(q);                       \
+    q = next_load();              \
+    if (++j == kb) {              \
+      finish_row(kb);             \
+      ++kb;                       \
+      j = strip;                  \
+      if (kb >= NB) break;        \
+    }
+    while (kb < NB) {
+      SCAML_LINV_STEP(q0)
+      SCAML_LINV_STEP(q1)
+      SCAML_LINV_STEP(q2)
+      SCAML_LINV_STEP(q3)
+      SCAML_LINV_STEP(q4)
+      SCAML_LINV_STEP(q5)
+      SCAML_LINV_STEP(q6)
+      SCAML_LINV_STEP(q7)
+    }
+#undef SCAML_LINV_STEP
   }
   }   // strips of this wave
 }
