@@ -280,7 +280,7 @@ __device__ __forceinline__ d4_t block_row_accumulate_deep(d4_t acc, const double
 
 __device__ __forceinline__ d4_t subst_accumulate(d4_t acc, const double* Lrow, bool row_ok, bool rows_in, int n, bool n_even,
                                                  const double* Vs, int j0, int kb, int lc, int lq) {
-  return block_row_accumulate<true>(acc, Lrow, row_ok, rows_in, n, n_even, Vs, j0, kb, lc, lq);
+  return block_row_accumulate_deep<true>(acc, Lrow, row_ok, rows_in, n, n_even, Vs, j0, kb, lc, lq);   // (four tiles ahead, buffers rotating in place)
 }
 
 }  // namespace scaml
