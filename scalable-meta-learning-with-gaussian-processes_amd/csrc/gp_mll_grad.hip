@@ -360,45 +360,48 @@ __global__ __launch_bounds__(256) void gp_mll_grad_kernel(MllGradParams p) {
   const int pa0 = 16 * ta0 + lc, pa1 = 16 * ta1 + lc, pc0 = 16 * tc0 + lc, pc1 = 16 * tc1 + lc;
   int r0 = 16 * ta0;
   if (ta1 < NB && 16 * ta1 + 16 <= N) {   // every column of the four blocks is inside the matrix
-    // (double-buffered: the 8 / 16 loads of the next trip are in flight while the 12 / 16 MFMAs of this one run --
-    //  a trip is otherwise one exposed L2 latency, ~5 x its MFMA time)
-    double na0[4], na1[4], nb0[4], nb1[4];
-    auto fetch = [&](int rr) {
-      const double* row = Li + (size_t)(rr + lq) * N;
+    // Two operand sets, alternating: the 16 loads of the trip after next are issued before the 12 / 16 MFMAs of this one, and no set is
+    // ever copied (round 3: the trip's operands used to be copied out of the set the next loads went into, and the compiler waited at
+    // the copy for the loads of one trip earlier -- an exposed L2 round trip per trip).  Unconditional buffer loads: a trip past the
+    // last row gets an offset beyond the descriptor's end and loads zeros.
+    typedef unsigned gk_u2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Li), 0, N * N * 8, 0x00020000);
+    struct OpSet {
+      double a0[4], a1[4], b0[4], b1[4];
+    };
+    auto fetch = [&](OpSet& o, int rr) {
+      const unsigned base = rr + 16 <= N ? (unsigned)(((size_t)(rr + lq) * N) * 8) : 0xC0000000u;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        na0[u] = row[(size_t)4 * u * N + pa0];
-        na1[u] = row[(size_t)4 * u * N + pa1];
-      }
-      if (!diag) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          nb0[u] = row[(size_t)4 * u * N + pc0];
-          nb1[u] = row[(size_t)4 * u * N + pc1];
-        }
+        const unsigned ro = base + (unsigned)(4 * u * N * 8);
+        o.a0[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsI, ro + (unsigned)(pa0 * 8), 0, 0));
+        o.a1[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsI, ro + (unsigned)(pa1 * 8), 0, 0));
+        o.b0[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsI, ro + (unsigned)(pc0 * 8), 0, 0));
+        o.b1[u] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsI, ro + (unsigned)(pc1 * 8), 0, 0));
       }
     };
-    if (r0 + 16 <= N) fetch(r0);
-    for (; r0 + 16 <= N; r0 += 16) {
-      double a0[4], a1[4], b0[4], b1[4];
+    auto mma = [&](const OpSet& o) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a0[u] = na0[u]; a1[u] = na1[u];
-        b0[u] = diag ? na0[u] : nb0[u];
-        b1[u] = diag ? na1[u] : nb1[u];
-      }
-      if (r0 + 32 <= N) fetch(r0 + 16);
+      for (int u = 0; u < 4; ++u) k00 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0[u], o.b0[u], k00, 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) k00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], k00, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) k10 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1[u], o.b0[u], k10, 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) k10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], k10, 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) k11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], k11, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) k11 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1[u], o.b1[u], k11, 0, 0, 0);
       if (!diag) {   // (the tile above the diagonal of a diagonal super-tile is not needed)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], k01, 0, 0, 0);
+        for (int u = 0; u < 4; ++u) k01 = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0[u], o.b1[u], k01, 0, 0, 0);
       }
+    };
+    OpSet s0, s1;
+    fetch(s0, r0);
+    fetch(s1, r0 + 16);
+    for (; r0 + 16 <= N; r0 += 32) {
+      mma(s0);
+      fetch(s0, r0 + 32);
+      if (r0 + 32 <= N) mma(s1);
+      fetch(s1, r0 + 48);
     }
+    r0 = N & ~15;   // (every whole block row done)
   }
   for (; r0 < N; r0 += 4) {
     const int r = r0 + lq;
