@@ -144,3 +144,24 @@ def test_full_stack_properties(device):
         torch.testing.assert_close(L[t].cpu(), ref["L"], rtol=1e-7, atol=1e-9)
         torch.testing.assert_close(out["alpha"][t].cpu(), ref["alpha"], rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(out["mll"][t].cpu(), ref["mll"], rtol=1e-3, atol=1e-9)
+
+
+def test_tiny_and_empty_tasks_agree_with_the_sequence_of_launches(device):
+    """n_t = 0, 1, 31, 33 next to a full task: rows / columns past n_t are an identity block that is never written (the one-launch
+    kernel's buffer descriptor of L ends at row n_t); both paths give the same factor, alpha and scalars (mll = 0 for the empty task)."""
+    T, N, D, kind = 5, 512, 3, O.KIND_MATERN52
+    X, y, theta = (t.to(device) for t in _stack(T, N, D, 77))
+    n = torch.tensor([0, 1, 31, 33, 512], dtype=torch.int32, device=device)
+    res = {}
+    was = _lib.lib.scaml_debug_blocked_fit_path(0)
+    try:
+        for path in (1, 2):
+            _lib.lib.scaml_debug_blocked_fit_path(path)
+            res[path] = ops.gp_fit_fused(X, y, theta, kind, n_points=n)
+            assert _took() == path and not res[path]["info"].cpu().any()
+    finally:
+        _lib.lib.scaml_debug_blocked_fit_path(was)
+    assert float(res[2]["mll"][0]) == 0.0
+    for k, tol in (("L", 1e-11), ("alpha", 1e-8), ("mll", 1e-10), ("logdet", 1e-9)):
+        torch.testing.assert_close(res[2][k], res[1][k], rtol=tol, atol=tol)
+    assert float(res[2]["alpha"][1, 1:].abs().sum()) == 0.0 and float(res[2]["L"][2, 31:, :].abs().sum()) == 0.0
